@@ -1,0 +1,197 @@
+/*
+ * libvslam_hip -- C ABI of the MI355X (gfx950) implementation of the
+ * VisualSLAM point-landmark hot path and corner front end.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, and
+ * returns a vslam_status (0 = ok, negative = error) instead of the
+ * reference's assert() aborts.  All matrices are column-major doubles, the
+ * layout of Eigen::MatrixXd, so a caller holding Eigen objects passes
+ * M.data(), M.rows(), M.outerStride() straight through.
+ *
+ * Two families:
+ *   - host-pointer entry points (no suffix): drop-in for the reference's call
+ *     sites; the library stages inputs to the device, runs the kernels on the
+ *     context's stream, copies the results back and synchronises.
+ *   - device-pointer entry points (_dev suffix): every pointer is device
+ *     memory; work is queued on the context's stream and NOT synchronised.
+ *     Batched variants take a batch count and element strides.
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to the reference checkout).
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t vslam_status;
+enum {
+    VSLAM_OK = 0,
+    VSLAM_ERR_ARG = -1,          /* null pointer / bad enum */
+    VSLAM_ERR_SHAPE = -2,        /* dimensions violate the reference's asserts */
+    VSLAM_ERR_DEVICE = -3,       /* HIP runtime error (see vslam_last_error) */
+    VSLAM_ERR_ALLOC = -4,
+    VSLAM_ERR_IO = -5,
+    VSLAM_ERR_CAPACITY = -6,     /* problem larger than a kernel's static limit */
+    VSLAM_ERR_UNSUPPORTED = -7   /* calibration flag outside RATIONAL|THIN_PRISM */
+};
+
+typedef struct vslam_ctx vslam_ctx;
+
+/* CameraParameters, src/cameraModel.hpp:12-23.  d[] is OpenCV's order
+ * k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4; flag is the OpenCV calibration flag
+ * (CALIB_RATIONAL_MODEL 0x4000, CALIB_THIN_PRISM_MODEL 0x8000). */
+typedef struct {
+    double fx, fy, cx, cy;
+    double d[12];
+    double fov_deg;              /* fieldOfView, 120 by default (not serialised) */
+    int32_t flag;
+    int32_t width, height;
+    int32_t reserved_;
+} vslam_camera;
+
+/* Feature, src/imagefeatures.h:15-19 */
+typedef struct { int32_t x, y; float score; } vslam_feature;
+
+typedef struct {
+    int32_t block_size;          /* structure-tensor window (odd, 3..15), 7 = cv::ORB's Harris */
+    int32_t border;              /* keypoints satisfy border <= x < w-border (>= block_size/2+2) */
+    int32_t max_features;        /* cap per detector (reference: 10000, src/SLAM.cpp:114) */
+    float harris_k;              /* 0.04 */
+    float harris_thresh;         /* keep if response > thresh (reference: 1e-4, src/SLAM.cpp:116) */
+    float shi_thresh;
+} vslam_corner_params;
+
+enum { VSLAM_LAYOUT_COMPAT = 0, VSLAM_LAYOUT_STRICT = 1 };
+enum { VSLAM_DETECTOR_HARRIS = 0, VSLAM_DETECTOR_SHI_TOMASI = 1 };
+
+/* ---- context ---- */
+/* Creates a context on `device` with its own non-blocking stream. */
+vslam_status vslam_ctx_create(int device, vslam_ctx **out);
+/* Same, but queues all work on the caller's hipStream_t (e.g. torch's current
+ * stream); the stream is borrowed, not destroyed. */
+vslam_status vslam_ctx_create_on_stream(int device, void *hip_stream, vslam_ctx **out);
+vslam_status vslam_ctx_destroy(vslam_ctx *ctx);
+vslam_status vslam_ctx_synchronize(vslam_ctx *ctx);
+const char *vslam_status_string(vslam_status s);
+const char *vslam_last_error(const vslam_ctx *ctx);
+/* 1 when the library was built with its gfx950 kernels (always, for this build). */
+int vslam_has_device_code(void);
+
+/* ---- camera.xml ----
+ * CameraParameters::read + importCalibrationData, src/cameraModel.cpp:71-77,93-100.
+ * Host only; parses the cv::FileStorage XML (<camera_matrix>,
+ * <distortion_coefficients>, <flag>, <imageSize>). */
+vslam_status vslam_camera_from_xml(const char *path, vslam_camera *cam);
+
+/* ---- projection ----
+ * worldToPixel<double>, src/cameraModel.hpp:32-216, for landmarks j0..j0+L-1
+ * of state x (n = 12 + 3*nLandmarks).  px[2L]; code[L] in {0,1,2}. Culled
+ * entries: code 2 keeps the computed pixel, code 1 writes NaN. */
+vslam_status vslam_project(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
+                           int j0, int L, double *px, int32_t *code);
+
+/* ---- measurement model ----
+ * MeasurementPointLandmarkBundle::operator(), src/measurementPointLandmark.cpp:13-70
+ * (which loops MeasurementPointLandmarkSingle, src/measurementPointLandmark.hpp:10-304).
+ * h[2L]; SR (2L x 2L, ld 2L) = 0.01*I or NULL; C (2L x n, ld 2L) or NULL;
+ * code[L] or NULL.  layout COMPAT reproduces the reference's column placement
+ * (0-2, 3-5, 6+3j) and its use of x(3..5) in the rotation block; STRICT places
+ * the blocks at 6-8, 9-11, 12+3j with the true pose angles. */
+vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
+                                  int layout, double *h, double *SR, double *C, int32_t *code);
+/* MeasurementPointLandmarkSingle::operator(), src/measurementPointLandmark.hpp:10,33,46.
+ * h[2], SR[4] or NULL, J (2 x n) or NULL; returns the projection code through *code. */
+vslam_status vslam_single_measure(vslam_ctx *ctx, const vslam_camera *cam, int j, const double *x, int n,
+                                  int layout, double *h, double *SR, double *J, int32_t *code);
+
+/* ---- point log-likelihood ----
+ * PointLogLikelihood::operator() x3, src/model.cpp:408-437 (value / gradient /
+ * exact Hessian of pointLogLikelihood, src/model.cpp:369-406).
+ * y[2L] = landmarks[j].pixel_measurement, visible[L] = landmarks[j].isVisible,
+ * sigma = measurement_noise.  g (n) and H (n x n, leading dimension ldH) may
+ * be NULL, selecting the 1-, 2- or 3-output arity.  code[L] may be NULL. */
+vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
+                                const double *y, const uint8_t *visible, double sigma,
+                                double *value, double *g, double *H, int ldH, int32_t *code);
+/* Device-pointer, strided-batch form: instance b reads x + b*stride_x etc.
+ * Strides are in elements; value has stride 1, code stride L. */
+vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, int batch, int n,
+                                          const double *x, size_t stride_x,
+                                          const double *y, size_t stride_y,
+                                          const uint8_t *visible, size_t stride_vis, double sigma,
+                                          double *value, double *g, size_t stride_g,
+                                          double *H, int ldH, size_t stride_H, int32_t *code);
+
+/* ---- Gaussian algebra ----
+ * logGaussian x3, src/gaussian.hpp:30-74.  S upper triangular sqrt-covariance. */
+vslam_status vslam_log_gaussian(vslam_ctx *ctx, const double *x, const double *mu, const double *S,
+                                int n, int ldS, double *value, double *g, double *H);
+/* The QR step of affineTransform, src/gaussian.hpp:117-127:
+ * Syy = triu(qr([S*C^T ; SR]))[0:m,0:m]; S n x n, C m x n, SR m x m. */
+vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n, int ldS,
+                               const double *C, int m, int ldC, const double *SR, int ldSR,
+                               double *Syy, int ldSyy);
+/* affineTransform(mux, Sxx, MeasurementPointLandmarkBundle, muy, Syy) as called at
+ * src/SLAM.cpp:371-387 and src/dataAssociation.cpp:53-61, fused on the device. */
+vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *cam, const double *mux,
+                                 const double *Sxx, int n, int ldS, int layout,
+                                 double *muy, double *Syy, int ldSyy, int32_t *code);
+/* Eigen::HouseholderQR + triangularView<Upper>, src/gaussian.hpp:121-124,515-516,
+ * src/SLAM.cpp:810-819: in place; R in the upper triangle, zeros below. */
+vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int cols, int lda);
+vslam_status vslam_qr_upper_batch_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda,
+                                      size_t stride_A, int batch);
+/* src/gaussian.hpp:513-516: S = triu(qr(diag(1/sqrt(v)) * Q^T)). */
+vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out);
+/* conditionGaussianOnMarginal, src/gaussian.cpp:19-36 (joint dim ny+nx, ld). */
+vslam_status vslam_condition_on_marginal(vslam_ctx *ctx, const double *muyx, const double *Syx,
+                                         int ny, int nx, int ld, const double *y,
+                                         double *mux_out, double *Sx_out, int ldo);
+
+/* ---- cost + measurement update ----
+ * CostJointDensity::operator() (g,H arity), src/gaussian.hpp:455-466, with
+ * PointLogLikelihood as the likelihood: V = -(logprior + loglik), g, H. */
+vslam_status vslam_cost_joint_density(vslam_ctx *ctx, const vslam_camera *cam, const double *x,
+                                      const double *mu, const double *S, int n, int ldS,
+                                      const double *y, const uint8_t *visible, double sigma,
+                                      double *value, double *g, double *H);
+/* measurementUpdateIEKF(mux, Sxx, u, y, PointLogLikelihood, param, muxGy, SxxGy),
+ * src/gaussian.hpp:469-532 as called at src/SLAM.cpp:492: trust-region Newton
+ * (src/fmin.hpp:19-107, src/fmin.cpp:40-131) on the host driving the device
+ * cost kernels, then the posterior square-root QR.  fmin_code: 0 converged,
+ * 1 iteration limit; iters / cost_evals optional. */
+vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *cam,
+                                           const double *mu, const double *S, int n, int ldS,
+                                           const double *y, const uint8_t *visible, double sigma,
+                                           double *mu_post, double *S_post, int ldSp,
+                                           int32_t *fmin_code, int32_t *iters, int32_t *cost_evals);
+
+/* ---- corner front end ----
+ * The feature stage of detectAndDrawORB, src/imagefeatures.cpp:71-96, reduced
+ * to what the caller consumes (src/SLAM.cpp:449-472): keypoints with a
+ * Harris (or Shi-Tomasi) response, sorted by response.  gray is w x h u8 with
+ * row stride `stride` bytes.  out[cap] receives min(count, cap, max_features)
+ * records sorted by score descending (ties: y, then x ascending); *count is
+ * the number written. */
+vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                 const vslam_corner_params *params, int detector,
+                                 vslam_feature *out, int cap, int32_t *count);
+/* Dense response maps (float32, w*h, row-major); either may be NULL. */
+vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                   const vslam_corner_params *params, float *harris, float *shi);
+/* Device-pointer batch: frames at gray + f*stride_frame; out + f*cap; count[f]. */
+vslam_status vslam_corner_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                           size_t stride_frame, int frames,
+                                           const vslam_corner_params *params, int detector,
+                                           vslam_feature *out, int cap, int32_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,272 @@
+"""ctypes binding of the CPU oracle (oracle/libvslam_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() -- never by the visualslam_amd package.
+All matrices are column-major float64 (numpy order='F'), like Eigen::MatrixXd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvslam_oracle.so")
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("d", C.c_double * 12), ("fov_deg", C.c_double),
+                ("flag", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class CornerParams(C.Structure):
+    _fields_ = [("block_size", C.c_int32), ("border", C.c_int32), ("max_features", C.c_int32),
+                ("harris_k", C.c_float), ("harris_thresh", C.c_float), ("shi_thresh", C.c_float)]
+
+
+FEATURE_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("score", np.float32)])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    return C.CDLL(_SO)
+
+
+_lib = _load()
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def _b(a):
+    return a.ctypes.data_as(_bp) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _F(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+_lib.orc_world_to_pixel.restype = C.c_int
+_lib.orc_single_measure.restype = C.c_int
+_lib.orc_point_loglik_value.restype = C.c_double
+_lib.orc_point_loglik_autodiff.restype = C.c_long
+_lib.orc_log_gaussian.restype = C.c_double
+_lib.orc_trs.restype = C.c_int
+_lib.orc_measurement_update_iekf.restype = C.c_int
+_lib.orc_corner_detect.restype = C.c_int
+
+
+def make_camera(fx, fy, cx, cy, dist, flag, width, height, fov_deg=120.0):
+    cam = Camera()
+    cam.fx, cam.fy, cam.cx, cam.cy = fx, fy, cx, cy
+    for i in range(12):
+        cam.d[i] = float(dist[i]) if i < len(dist) else 0.0
+    cam.fov_deg, cam.flag, cam.width, cam.height = fov_deg, flag, width, height
+    return cam
+
+
+def rot(kind, a):
+    R = np.zeros((3, 3), order="F")
+    getattr(_lib, "orc_rot" + kind)(C.c_double(a), _d(R))
+    return R
+
+
+def rpy2rot(theta):
+    R = np.zeros((3, 3), order="F")
+    _lib.orc_rpy2rot(_d(_f64(theta)), _d(R))
+    return R
+
+
+def rot2rpy(R):
+    th = np.zeros(3)
+    _lib.orc_rot2rpy(_d(_F(R)), _d(th))
+    return th
+
+
+def world_to_pixel(r, eta, cam):
+    px = np.full(2, np.nan)
+    code = _lib.orc_world_to_pixel(_d(_f64(r)), _d(_f64(eta)), C.byref(cam), _d(px))
+    return code, px
+
+
+def single_measure(j, x, cam, layout=0, want_J=True):
+    x = _f64(x)
+    n = x.size
+    h = np.full(2, np.nan)
+    SR = np.zeros((2, 2), order="F")
+    J = np.zeros((2, n), order="F") if want_J else None
+    code = _lib.orc_single_measure(j, _d(x), n, C.byref(cam), layout, _d(h), _d(SR), _d(J))
+    return code, h, SR, J
+
+
+def bundle_measure(x, cam, layout=0, want_SR=True, want_C=True):
+    x = _f64(x)
+    n = x.size
+    L = (n - 12) // 3
+    h = np.zeros(2 * L)
+    SR = np.zeros((2 * L, 2 * L), order="F") if want_SR else None
+    Cm = np.zeros((2 * L, n), order="F") if want_C else None
+    code = np.zeros(L, dtype=np.int32)
+    _lib.orc_bundle_measure(_d(x), n, C.byref(cam), layout, _d(h), _d(SR), _d(Cm), _i(code))
+    return h, SR, Cm, code
+
+
+def point_loglik_value(x, y, visible, cam, sigma):
+    x, y = _f64(x), _f64(y)
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    code = np.zeros(vis.size, dtype=np.int32)
+    v = _lib.orc_point_loglik_value(_d(x), x.size, _d(y), _b(vis), C.byref(cam), C.c_double(sigma), _i(code))
+    return v, code
+
+
+def _lik(fn, x, y, visible, cam, sigma, with_code=True):
+    x, y = _f64(x), _f64(y)
+    n = x.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    val = C.c_double(0.0)
+    g = np.zeros(n)
+    H = np.zeros((n, n), order="F")
+    code = np.zeros(vis.size, dtype=np.int32)
+    args = [_d(x), n, _d(y), _b(vis), C.byref(cam), C.c_double(sigma), C.byref(val), _d(g), _d(H)]
+    if with_code:
+        args.append(_i(code))
+    fn(*args)
+    return val.value, g, H, code
+
+
+def point_loglik_dual_sparse(x, y, visible, cam, sigma):
+    return _lik(_lib.orc_point_loglik_dual_sparse, x, y, visible, cam, sigma)
+
+
+def point_loglik_analytic(x, y, visible, cam, sigma):
+    return _lik(_lib.orc_point_loglik_analytic, x, y, visible, cam, sigma)
+
+
+def point_loglik_autodiff(x, y, visible, cam, sigma, row_begin=0, row_end=None):
+    """Reference-faithful n(n+1)/2-pass evaluation; returns (value, g, H, passes)."""
+    x, y = _f64(x), _f64(y)
+    n = x.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    val = C.c_double(0.0)
+    g = np.zeros(n)
+    H = np.zeros((n, n), order="F")
+    row_end = n if row_end is None else row_end
+    passes = _lib.orc_point_loglik_autodiff(_d(x), n, _d(y), _b(vis), C.byref(cam), C.c_double(sigma),
+                                            row_begin, row_end, C.byref(val), _d(g), _d(H))
+    return val.value, g, H, passes
+
+
+def log_gaussian(x, mu, S, want_g=True, want_H=True):
+    x, mu, S = _f64(x), _f64(mu), _F(S)
+    n = x.size
+    g = np.zeros(n) if want_g else None
+    H = np.zeros((n, n), order="F") if want_H else None
+    v = _lib.orc_log_gaussian(_d(x), _d(mu), _d(S), n, n, _d(g), _d(H))
+    return v, g, H
+
+
+def qr_upper(A):
+    A = np.array(A, dtype=np.float64, order="F", copy=True)
+    _lib.orc_qr_upper(_d(A), A.shape[0], A.shape[1], A.shape[0])
+    return A
+
+
+def affine_sqrt(S, Cm, SR):
+    S, Cm, SR = _F(S), _F(Cm), _F(SR)
+    n, m = S.shape[0], Cm.shape[0]
+    Syy = np.zeros((m, m), order="F")
+    _lib.orc_affine_sqrt(_d(S), n, n, _d(Cm), m, m, _d(SR), m, _d(Syy), m)
+    return Syy
+
+
+def condition_on_marginal(muyx, Syx, y):
+    muyx, Syx, y = _f64(muyx), _F(Syx), _f64(y)
+    ny = y.size
+    nx = muyx.size - ny
+    mu = np.zeros(nx)
+    Sx = np.zeros((nx, nx), order="F")
+    _lib.orc_condition_on_marginal(_d(muyx), _d(Syx), ny, nx, ny + nx, _d(y), _d(mu), _d(Sx), nx)
+    return mu, Sx
+
+
+def iekf_post_sqrt(Q, v):
+    Q, v = _F(Q), _f64(v)
+    n = v.size
+    S = np.zeros((n, n), order="F")
+    _lib.orc_iekf_post_sqrt(_d(Q), _d(v), n, _d(S))
+    return S
+
+
+def sym_eig(H):
+    H = _F(H)
+    n = H.shape[0]
+    Q = np.zeros((n, n), order="F")
+    v = np.zeros(n)
+    _lib.orc_sym_eig(_d(H), n, _d(Q), _d(v))
+    return Q, v
+
+
+def trs(Q, v, g, D):
+    Q, v, g = _F(Q), _f64(v), _f64(g)
+    p = np.zeros(v.size)
+    ret = _lib.orc_trs(_d(Q), _d(v), _d(g), v.size, C.c_double(D), _d(p))
+    return ret, p
+
+
+def measurement_update_iekf(mu, S, y, visible, cam, sigma):
+    mu, S, y = _f64(mu), _F(S), _f64(y)
+    n = mu.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    mup = np.zeros(n)
+    Sp = np.zeros((n, n), order="F")
+    it, ev = C.c_int(0), C.c_int(0)
+    ret = _lib.orc_measurement_update_iekf(_d(mu), _d(S), n, _d(y), _b(vis), C.byref(cam), C.c_double(sigma),
+                                           _d(mup), _d(Sp), C.byref(it), C.byref(ev))
+    return ret, mup, Sp, it.value, ev.value
+
+
+def corner_params(block_size=7, border=None, max_features=10000, harris_k=0.04,
+                  harris_thresh=1e-4, shi_thresh=1e-3):
+    p = CornerParams()
+    p.block_size = block_size
+    p.border = (block_size // 2 + 2) if border is None else border
+    p.max_features = max_features
+    p.harris_k, p.harris_thresh, p.shi_thresh = harris_k, harris_thresh, shi_thresh
+    return p
+
+
+def corner_response(gray, params):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    har = np.zeros((h, w), dtype=np.float32)
+    shi = np.zeros((h, w), dtype=np.float32)
+    _lib.orc_corner_response(_b(gray), w, h, w, C.byref(params),
+                             har.ctypes.data_as(C.POINTER(C.c_float)), shi.ctypes.data_as(C.POINTER(C.c_float)))
+    return har, shi
+
+
+def corner_detect(gray, params, which, cap=None):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    cap = params.max_features if cap is None else cap
+    out = np.zeros(cap, dtype=FEATURE_DTYPE)
+    n = _lib.orc_corner_detect(_b(gray), w, h, w, C.byref(params), which, out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n].copy()

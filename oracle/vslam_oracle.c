@@ -1,0 +1,1047 @@
+/*
+ * CPU oracle for the VisualSLAM point-landmark hot path -- see vslam_oracle.h.
+ * TEST INFRASTRUCTURE ONLY; never linked into the shipped library.
+ *
+ * Plain C, scalar, single-threaded (the reference has no threading).  Every
+ * function cites the reference lines it restates (paths relative to the
+ * reference checkout).  No reference source text is reproduced here.
+ */
+#include "vslam_oracle.h"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846264338327950288
+#endif
+
+#define ORC_RATIONAL 0x4000   /* cv::CALIB_RATIONAL_MODEL */
+#define ORC_THINPRISM 0x8000  /* cv::CALIB_THIN_PRISM_MODEL */
+
+/* ------------------------------------------------------------------ */
+/* small 3x3 helpers (column-major, M[r + 3*c])                        */
+/* ------------------------------------------------------------------ */
+static void mat3_mul(const double *A, const double *B, double *C)
+{
+    double T[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += A[r + 3 * k] * B[k + 3 * c];
+            T[r + 3 * c] = s;
+        }
+    memcpy(C, T, sizeof T);
+}
+static void mat3_tvec(const double *A, const double *v, double *out) /* out = A^T v */
+{
+    for (int c = 0; c < 3; ++c)
+        out[c] = A[0 + 3 * c] * v[0] + A[1 + 3 * c] * v[1] + A[2 + 3 * c] * v[2];
+}
+static void mat3_vec(const double *A, const double *v, double *out) /* out = A v */
+{
+    for (int r = 0; r < 3; ++r)
+        out[r] = A[r + 0] * v[0] + A[r + 3] * v[1] + A[r + 6] * v[2];
+}
+
+/* src/rotation.hpp:22-30 */
+void orc_rotx(double a, double *R)
+{
+    double c = cos(a), s = sin(a);
+    R[0] = 1; R[3] = 0; R[6] = 0;
+    R[1] = 0; R[4] = c; R[7] = -s;
+    R[2] = 0; R[5] = s; R[8] = c;
+}
+/* src/rotation.hpp:32-40 */
+void orc_roty(double a, double *R)
+{
+    double c = cos(a), s = sin(a);
+    R[0] = c;  R[3] = 0; R[6] = s;
+    R[1] = 0;  R[4] = 1; R[7] = 0;
+    R[2] = -s; R[5] = 0; R[8] = c;
+}
+/* src/rotation.hpp:42-50 */
+void orc_rotz(double a, double *R)
+{
+    double c = cos(a), s = sin(a);
+    R[0] = c; R[3] = -s; R[6] = 0;
+    R[1] = s; R[4] = c;  R[7] = 0;
+    R[2] = 0; R[5] = 0;  R[8] = 1;
+}
+/* src/rotation.hpp:52-63: Rnc = Rz(psi) Ry(theta) Rx(phi), theta = (phi,theta,psi) */
+void orc_rpy2rot(const double *th, double *R)
+{
+    double Rx[9], Ry[9], Rz[9], T[9];
+    orc_rotz(th[2], Rz);
+    orc_roty(th[1], Ry);
+    orc_rotx(th[0], Rx);
+    mat3_mul(Rz, Ry, T);
+    mat3_mul(T, Rx, R);
+}
+/* src/rotation.hpp:13-20 */
+void orc_rot2rpy(const double *R, double *th)
+{
+    th[0] = atan2(R[2 + 3 * 1], R[2 + 3 * 2]);
+    th[1] = atan2(-R[2 + 3 * 0], sqrt(pow(R[2 + 3 * 1], 2) + pow(R[2 + 3 * 2], 2)));
+    th[2] = atan2(R[1 + 3 * 0], R[0 + 3 * 0]);
+}
+
+/* Distortion-coefficient selection, src/cameraModel.hpp:114-148 (the gating
+ * is swapped relative to OpenCV's naming; reproduced as written). */
+typedef struct { double fx, fy, cx, cy, k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4; } coeffs;
+static void select_coeffs(const orc_camera *cam, coeffs *k)
+{
+    int rational = (cam->flag & ORC_RATIONAL) == ORC_RATIONAL;
+    int thin = (cam->flag & ORC_THINPRISM) == ORC_THINPRISM;
+    assert((cam->flag & ~(ORC_RATIONAL | ORC_THINPRISM)) == 0);
+    k->fx = cam->fx; k->fy = cam->fy; k->cx = cam->cx; k->cy = cam->cy;
+    k->k1 = cam->d[0]; k->k2 = cam->d[1]; k->p1 = cam->d[2]; k->p2 = cam->d[3]; k->k3 = cam->d[4];
+    if (rational) {
+        if (thin) { k->s1 = cam->d[8]; k->s2 = cam->d[9]; k->s3 = cam->d[10]; k->s4 = cam->d[11]; }
+        else      { k->s1 = cam->d[5]; k->s2 = cam->d[6]; k->s3 = cam->d[7];  k->s4 = cam->d[8]; }
+    } else { k->s1 = k->s2 = k->s3 = k->s4 = 0.0; }
+    if (thin) { k->k4 = cam->d[5]; k->k5 = cam->d[6]; k->k6 = cam->d[7]; }
+    else      { k->k4 = k->k5 = k->k6 = 0.0; }
+}
+
+/* src/cameraModel.hpp:32-216 */
+int orc_world_to_pixel(const double *rPNn, const double *eta, const orc_camera *cam, double *px)
+{
+    double Rnc[9], d[3], q[3];
+    orc_rpy2rot(eta + 3, Rnc);
+    for (int i = 0; i < 3; ++i) d[i] = rPNn[i] - eta[i];
+    mat3_tvec(Rnc, d, q);                                   /* :61 */
+    double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double uz = q[2] / nrm;                                 /* :63 */
+    double cAngle = cos(cam->fov_deg * ((M_PI / 180.0) / 2.)); /* :67-68 */
+    if (uz < cAngle) return 1;                              /* :70-75 */
+    coeffs k; select_coeffs(cam, &k);
+    if (q[2] <= 0) return 1;                                /* :179-181 */
+    double u = q[0] / q[2], v = q[1] / q[2];
+    double u2 = u * u, v2 = v * v, r2 = u2 + v2, r4 = r2 * r2, r6 = r4 * r2;
+    double alpha = k.k1 * r2 + k.k2 * r4 + k.k3 * r6;
+    double beta = k.k4 * r2 + k.k5 * r4 + k.k6 * r6;
+    double c = (1.0 + alpha) / (1.0 + beta);
+    double up = c * u + k.p1 * 2 * u * v + k.p2 * (r2 + 2 * u2) + k.s1 * r2 + k.s2 * r4;
+    double vp = c * v + k.p2 * 2 * u * v + k.p1 * (r2 + 2 * v2) + k.s3 * r2 + k.s4 * r4;
+    px[0] = k.fx * up + k.cx;                               /* :202 */
+    px[1] = k.fy * vp + k.cy;
+    int inW = 0 <= px[0] && px[0] <= cam->width - 1;        /* :204-213 */
+    int inH = 0 <= px[1] && px[1] <= cam->height - 1;
+    if (!(inW && inH)) return 2;
+    return 0;
+}
+
+/* src/measurementPointLandmark.hpp:10-304 */
+int orc_single_measure(int j, const double *x, int n, const orc_camera *cam, int layout,
+                       double *h, double *SR, double *J)
+{
+    const double *eta = x + 6;
+    const double *rP = x + 12 + 3 * j;
+    int res = orc_world_to_pixel(rP, eta, cam, h);          /* :26-28 */
+    if (SR) { SR[0] = 0.01; SR[1] = 0.0; SR[2] = 0.0; SR[3] = 0.01; } /* :35-41 */
+    if (!J) return res;
+    memset(J, 0, sizeof(double) * 2 * (size_t)n);           /* :56-57 */
+
+    double Rnc[9], d[3], q[3];
+    orc_rpy2rot(eta + 3, Rnc);                              /* :72 */
+    for (int i = 0; i < 3; ++i) d[i] = rP[i] - eta[i];
+    mat3_tvec(Rnc, d, q);                                   /* :74 */
+    coeffs k; select_coeffs(cam, &k);
+    double X = q[0], Y = q[1], Z = q[2], u, v;
+    if (Z <= 0) { u = 0; v = 0; } else { u = X / Z; v = Y / Z; }   /* :175-181 */
+    double u2 = u * u, v2 = v * v, r2 = u2 + v2, r = sqrt(r2), r3 = r2 * r;
+    double r4 = r2 * r2, r5 = r4 * r, r6 = r4 * r2;
+    double alpha = k.k1 * r2 + k.k2 * r4 + k.k3 * r6;
+    double beta = k.k4 * r2 + k.k5 * r4 + k.k6 * r6;
+    double c = (1.0 + alpha) / (1.0 + beta);
+    double dudr[3], dvdr[3];
+    if (Z <= 0) { dudr[0] = dudr[1] = dudr[2] = 0; dvdr[0] = dvdr[1] = dvdr[2] = 0; } /* :208-214 */
+    else {
+        dudr[0] = 1 / Z; dudr[1] = 0; dudr[2] = -X / (Z * Z);
+        dvdr[0] = 0; dvdr[1] = 1 / Z; dvdr[2] = -Y / (Z * Z);
+    }
+    double drdu = (u != 0) ? pow(u2 + v2, -0.5) * u : 0;    /* :216-227 */
+    double drdv = (v != 0) ? pow(u2 + v2, -0.5) * v : 0;
+    double dalphadr = 2 * k.k1 * r + 4 * k.k2 * r3 + 6 * k.k3 * r5;  /* :229-232 */
+    double dbetadr = 2 * k.k4 * r + 4 * k.k5 * r3 + 6 * k.k6 * r5;
+    double dcdr = (dalphadr * (1 + beta) - (1 + alpha) * dbetadr) / ((1 + beta) * (1 + beta));
+    double duddu = dcdr * drdu * u + c + 2 * k.p1 * v + k.p2 * (2 * r * drdu + 4 * u) + 2 * k.s1 * r * drdu + 4 * k.s2 * r3 * drdu;
+    double duddv = dcdr * drdv * u + 2 * k.p1 * u + k.p2 * (2 * r * drdv) + 2 * k.s1 * r * drdv + 4 * k.s2 * r3 * drdv;
+    double dvddu = dcdr * drdu * v + 2 * k.p2 * v + k.p1 * (2 * r * drdu) + 2 * k.s3 * r * drdu + 4 * k.s4 * r3 * drdu;
+    double dvddv = dcdr * drdv * v + c + 2 * k.p2 * u + k.p1 * (2 * r * drdv + 4 * v) + 2 * k.s3 * r * drdv + 4 * k.s4 * r3 * drdv;
+    double JrPCc[6]; /* 2x3 col-major */                    /* :249-254 */
+    for (int i = 0; i < 3; ++i) {
+        JrPCc[0 + 2 * i] = k.fx * (duddu * dudr[i] + duddv * dvdr[i]);
+        JrPCc[1 + 2 * i] = k.fy * (dvddu * dudr[i] + dvddv * dvdr[i]);
+    }
+    double JrPNn[6];                                        /* :256: JrPCc * Rnc^T */
+    for (int r_ = 0; r_ < 2; ++r_)
+        for (int c_ = 0; c_ < 3; ++c_) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += JrPCc[r_ + 2 * t] * Rnc[c_ + 3 * t];
+            JrPNn[r_ + 2 * c_] = s;
+        }
+    /* rotation block, :260-292.  COMPAT builds RX,RY,RZ from x(3),x(4),x(5). */
+    const double *ang = (layout == 0) ? (x + 3) : (x + 9);
+    double RX[9], RY[9], RZ[9], T[9], dPhi[9], dTheta[9], dPsi[9];
+    static const double S1[9] = {0, 0, 0, 0, 0, 1, 0, -1, 0};   /* rows: 0 0 0 / 0 0 -1 / 0 1 0 */
+    static const double S2[9] = {0, 0, -1, 0, 0, 0, 1, 0, 0};   /* rows: 0 0 1 / 0 0 0 / -1 0 0 */
+    static const double S3[9] = {0, 1, 0, -1, 0, 0, 0, 0, 0};   /* rows: 0 -1 0 / 1 0 0 / 0 0 0 */
+    orc_rotx(ang[0], RX); orc_roty(ang[1], RY); orc_rotz(ang[2], RZ);
+    mat3_mul(RZ, S3, T); mat3_mul(T, RY, T); mat3_mul(T, RX, dPsi);     /* :286 */
+    mat3_mul(RZ, RY, T); mat3_mul(T, S2, T); mat3_mul(T, RX, dTheta);   /* :287 */
+    mat3_mul(RZ, RY, T); mat3_mul(T, RX, T); mat3_mul(T, S1, dPhi);     /* :288 */
+    double JRnc[6], t3[3];
+    const double *dR[3] = {dPhi, dTheta, dPsi};
+    for (int a = 0; a < 3; ++a) {                           /* :290-292 */
+        mat3_tvec(dR[a], d, t3);
+        for (int r_ = 0; r_ < 2; ++r_)
+            JRnc[r_ + 2 * a] = JrPCc[r_ + 0] * t3[0] + JrPCc[r_ + 2] * t3[1] + JrPCc[r_ + 4] * t3[2];
+    }
+    int c0 = (layout == 0) ? 0 : 6, c1 = (layout == 0) ? 3 : 9;
+    int c2 = (layout == 0) ? 6 + 3 * j : 12 + 3 * j;        /* :294-296 */
+    for (int a = 0; a < 3; ++a)
+        for (int r_ = 0; r_ < 2; ++r_) {
+            J[r_ + 2 * (c0 + a)] = -JrPNn[r_ + 2 * a];
+            J[r_ + 2 * (c1 + a)] = JRnc[r_ + 2 * a];
+            J[r_ + 2 * (c2 + a)] = JrPNn[r_ + 2 * a];
+        }
+    return res;
+}
+
+/* src/measurementPointLandmark.cpp:13-70 */
+void orc_bundle_measure(const double *x, int n, const orc_camera *cam, int layout,
+                        double *h, double *SR, double *C, int32_t *code)
+{
+    int L = (n - 12) / 3, m = 2 * L;
+    double *Jt = C ? (double *)malloc(sizeof(double) * 2 * (size_t)n) : NULL;
+    if (C) memset(C, 0, sizeof(double) * (size_t)m * n);
+    for (int j = 0; j < L; ++j) {
+        double hj[2] = {NAN, NAN};
+        int res = orc_single_measure(j, x, n, cam, layout, hj, NULL, Jt);
+        h[2 * j] = hj[0]; h[2 * j + 1] = hj[1];
+        if (code) code[j] = res;
+        if (C)
+            for (int c = 0; c < n; ++c) {                   /* :64 */
+                C[(2 * j) + (size_t)m * c] = Jt[0 + 2 * c];
+                C[(2 * j + 1) + (size_t)m * c] = Jt[1 + 2 * c];
+            }
+    }
+    if (SR) {                                               /* :67-69 */
+        memset(SR, 0, sizeof(double) * (size_t)m * m);
+        for (int i = 0; i < m; ++i) SR[i + (size_t)m * i] = 0.01;
+    }
+    free(Jt);
+}
+
+/* src/model.cpp:369-406 with logGaussian (src/gaussian.hpp:30-46) on S = sigma*I2 */
+double orc_point_loglik_value(const double *x, int n, const double *y, const uint8_t *visible,
+                              const orc_camera *cam, double sigma, int32_t *code)
+{
+    int L = (n - 12) / 3;
+    double cost = 0.0;
+    for (int j = 0; j < L; ++j) {
+        double px[2];
+        int flag = orc_world_to_pixel(x + 12 + 3 * j, x + 6, cam, px);
+        if (code) code[j] = flag;
+        if (!visible[j] || flag != 0) continue;
+        double z0 = (y[2 * j] - px[0]) / sigma, z1 = (y[2 * j + 1] - px[1]) / sigma;
+        double log_sum = log(fabs(sigma)) + log(fabs(sigma));
+        cost += -0.5 * (z0 * z0 + z1 * z1) - 2.0 / 2 * log(2 * M_PI) - log_sum;
+    }
+    return cost;
+}
+
+/* ------------------------------------------------------------------ */
+/* second-order dual numbers: f + a e1 + b e2 + ab e1 e2               */
+/* (what autodiff::dual2nd carries: 4 doubles)                          */
+/* ------------------------------------------------------------------ */
+typedef struct { double v, a, b, ab; } d2;
+static inline d2 d2k(double c) { d2 r = {c, 0, 0, 0}; return r; }
+static inline d2 d2add(d2 x, d2 y) { d2 r = {x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; return r; }
+static inline d2 d2sub(d2 x, d2 y) { d2 r = {x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; return r; }
+static inline d2 d2neg(d2 x) { d2 r = {-x.v, -x.a, -x.b, -x.ab}; return r; }
+static inline d2 d2mul(d2 x, d2 y)
+{
+    d2 r = {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b,
+            x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
+    return r;
+}
+static inline d2 d2scale(double s, d2 x) { d2 r = {s * x.v, s * x.a, s * x.b, s * x.ab}; return r; }
+static inline d2 d2fun(d2 x, double f, double f1, double f2)
+{
+    d2 r = {f, f1 * x.a, f1 * x.b, f1 * x.ab + f2 * x.a * x.b};
+    return r;
+}
+static inline d2 d2div(d2 x, d2 y)
+{
+    double iv = 1.0 / y.v;
+    return d2mul(x, d2fun(y, iv, -iv * iv, 2 * iv * iv * iv));
+}
+static inline d2 d2sin(d2 x) { double s = sin(x.v), c = cos(x.v); return d2fun(x, s, c, -s); }
+static inline d2 d2cos(d2 x) { double s = sin(x.v), c = cos(x.v); return d2fun(x, c, -s, -c); }
+static inline d2 d2sqrt(d2 x) { double s = sqrt(x.v); return d2fun(x, s, 0.5 / s, -0.25 / (s * x.v)); }
+
+static void d2mat3_mul(const d2 *A, const d2 *B, d2 *C)
+{
+    d2 T[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            d2 s = d2mul(A[r], B[3 * c]);
+            s = d2add(s, d2mul(A[r + 3], B[1 + 3 * c]));
+            s = d2add(s, d2mul(A[r + 6], B[2 + 3 * c]));
+            T[r + 3 * c] = s;
+        }
+    memcpy(C, T, sizeof T);
+}
+
+/* worldToPixel<dual2nd>, src/cameraModel.hpp:32-216, including the dense
+ * 3x3 products of rpy2rot and the unused r = sqrt(r2). */
+static int d2_world_to_pixel(const d2 *rP, const d2 *eta, const orc_camera *cam, const coeffs *k, d2 *px)
+{
+    d2 Rx[9], Ry[9], Rz[9], R[9];
+    d2 cph = d2cos(eta[3]), sph = d2sin(eta[3]);
+    d2 cth = d2cos(eta[4]), sth = d2sin(eta[4]);
+    d2 cps = d2cos(eta[5]), sps = d2sin(eta[5]);
+    d2 one = d2k(1), zero = d2k(0);
+    Rx[0] = one;  Rx[3] = zero; Rx[6] = zero;
+    Rx[1] = zero; Rx[4] = cph;  Rx[7] = d2neg(sph);
+    Rx[2] = zero; Rx[5] = sph;  Rx[8] = cph;
+    Ry[0] = cth;  Ry[3] = zero; Ry[6] = sth;
+    Ry[1] = zero; Ry[4] = one;  Ry[7] = zero;
+    Ry[2] = d2neg(sth); Ry[5] = zero; Ry[8] = cth;
+    Rz[0] = cps;  Rz[3] = d2neg(sps); Rz[6] = zero;
+    Rz[1] = sps;  Rz[4] = cps;  Rz[7] = zero;
+    Rz[2] = zero; Rz[5] = zero; Rz[8] = one;
+    d2mat3_mul(Rz, Ry, R);
+    d2mat3_mul(R, Rx, R);
+    d2 d[3], q[3];
+    for (int i = 0; i < 3; ++i) d[i] = d2sub(rP[i], eta[i]);
+    for (int c = 0; c < 3; ++c) {
+        d2 s = d2mul(R[3 * c], d[0]);
+        s = d2add(s, d2mul(R[1 + 3 * c], d[1]));
+        s = d2add(s, d2mul(R[2 + 3 * c], d[2]));
+        q[c] = s;
+    }
+    d2 nrm = d2sqrt(d2add(d2add(d2mul(q[0], q[0]), d2mul(q[1], q[1])), d2mul(q[2], q[2])));
+    d2 uq2 = d2div(q[2], nrm);
+    double cAngle = cos(cam->fov_deg * ((M_PI / 180.0) / 2.));
+    if (uq2.v < cAngle) return 1;
+    if (q[2].v <= 0) return 1;
+    d2 u = d2div(q[0], q[2]), v = d2div(q[1], q[2]);
+    d2 u2 = d2mul(u, u), v2 = d2mul(v, v), r2 = d2add(u2, v2);
+    volatile double r_unused = sqrt(r2.v); (void)r_unused;   /* :192, value only matters for cost */
+    d2 r4 = d2mul(r2, r2), r6 = d2mul(r4, r2);
+    d2 alpha = d2add(d2add(d2scale(k->k1, r2), d2scale(k->k2, r4)), d2scale(k->k3, r6));
+    d2 beta = d2add(d2add(d2scale(k->k4, r2), d2scale(k->k5, r4)), d2scale(k->k6, r6));
+    d2 c = d2div(d2add(one, alpha), d2add(one, beta));
+    d2 uv = d2mul(u, v);
+    d2 up = d2add(d2add(d2add(d2add(d2mul(c, u), d2scale(k->p1 * 2, uv)),
+                              d2scale(k->p2, d2add(r2, d2scale(2, u2)))),
+                        d2scale(k->s1, r2)), d2scale(k->s2, r4));
+    d2 vp = d2add(d2add(d2add(d2add(d2mul(c, v), d2scale(k->p2 * 2, uv)),
+                              d2scale(k->p1, d2add(r2, d2scale(2, v2)))),
+                        d2scale(k->s3, r2)), d2scale(k->s4, r4));
+    px[0] = d2add(d2scale(k->fx, up), d2k(k->cx));
+    px[1] = d2add(d2scale(k->fy, vp), d2k(k->cy));
+    int inW = 0 <= px[0].v && px[0].v <= cam->width - 1;
+    int inH = 0 <= px[1].v && px[1].v <= cam->height - 1;
+    if (!(inW && inH)) return 2;
+    return 0;
+}
+
+/* one landmark term of src/model.cpp:392-404 on dual numbers */
+static int d2_landmark_term(const d2 *eta, const d2 *rP, const double *yj, const orc_camera *cam,
+                            const coeffs *k, double sigma, d2 *term)
+{
+    d2 px[2];
+    int flag = d2_world_to_pixel(rP, eta, cam, k, px);
+    if (flag != 0) return flag;
+    d2 z0 = d2scale(1.0 / sigma, d2sub(d2k(yj[0]), px[0]));
+    d2 z1 = d2scale(1.0 / sigma, d2sub(d2k(yj[1]), px[1]));
+    d2 sq = d2add(d2mul(z0, z0), d2mul(z1, z1));
+    double cst = -2.0 / 2 * log(2 * M_PI) - (log(fabs(sigma)) + log(fabs(sigma)));
+    *term = d2add(d2scale(-0.5, sq), d2k(cst));
+    return 0;
+}
+
+/* autodiff::hessian pass structure on src/model.cpp:427-437: one full
+ * likelihood evaluation per seed pair (i, j>=i). */
+long orc_point_loglik_autodiff(const double *x, int n, const double *y, const uint8_t *visible,
+                               const orc_camera *cam, double sigma, int row_begin, int row_end,
+                               double *value, double *g, double *H)
+{
+    int L = (n - 12) / 3;
+    coeffs k; select_coeffs(cam, &k);
+    d2 *xd = (d2 *)malloc(sizeof(d2) * (size_t)n);
+    long passes = 0;
+    for (int i = 0; i < n; ++i) xd[i] = d2k(x[i]);
+    for (int i = row_begin; i < row_end; ++i) {
+        for (int j = i; j < n; ++j) {
+            xd[i].a = 1.0;
+            xd[j].b = 1.0;
+            d2 cost = d2k(0);
+            for (int l = 0; l < L; ++l) {
+                if (!visible[l]) continue;
+                d2 term;
+                if (d2_landmark_term(xd + 6, xd + 12 + 3 * l, y + 2 * l, cam, &k, sigma, &term) == 0)
+                    cost = d2add(cost, term);
+            }
+            xd[i].a = 0.0;
+            xd[j].b = 0.0;
+            ++passes;
+            if (H) { H[i + (size_t)n * j] = cost.ab; H[j + (size_t)n * i] = cost.ab; }
+            if (g) g[i] = cost.a;
+            if (value) *value = cost.v;
+        }
+    }
+    free(xd);
+    return passes;
+}
+
+void orc_point_loglik_dual_sparse(const double *x, int n, const double *y, const uint8_t *visible,
+                                  const orc_camera *cam, double sigma,
+                                  double *value, double *g, double *H, int32_t *code)
+{
+    int L = (n - 12) / 3;
+    coeffs k; select_coeffs(cam, &k);
+    if (g) memset(g, 0, sizeof(double) * (size_t)n);
+    if (H) memset(H, 0, sizeof(double) * (size_t)n * n);
+    double val = 0.0;
+    for (int l = 0; l < L; ++l) {
+        int idx[9];
+        for (int a = 0; a < 6; ++a) idx[a] = 6 + a;
+        for (int a = 0; a < 3; ++a) idx[6 + a] = 12 + 3 * l + a;
+        d2 z[9];
+        for (int a = 0; a < 9; ++a) z[a] = d2k(x[idx[a]]);
+        d2 term;
+        int flag = d2_landmark_term(z, z + 6, y + 2 * l, cam, &k, sigma, &term);
+        if (code) code[l] = flag;
+        if (!visible[l] || flag != 0) continue;
+        val += term.v;
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b) {
+                z[a].a = 1.0; z[b].b = 1.0;
+                d2_landmark_term(z, z + 6, y + 2 * l, cam, &k, sigma, &term);
+                z[a].a = 0.0; z[b].b = 0.0;
+                if (H) {
+                    H[idx[a] + (size_t)n * idx[b]] += term.ab;
+                    if (a != b) H[idx[b] + (size_t)n * idx[a]] += term.ab;
+                }
+                if (g && b == a) g[idx[a]] += term.a;
+            }
+    }
+    if (value) *value = val;
+}
+
+/* ------------------------------------------------------------------ */
+/* closed-form gradient and exact Hessian                               */
+/* ------------------------------------------------------------------ */
+/* Distortion map D(u,v) of src/cameraModel.hpp:189-201 with first and second
+ * partials w.r.t. (u,v), written through r2 = u^2+v^2 (smooth at the axis). */
+static void distort_d2(const coeffs *k, double u, double v, double *D, double *JD /*2x2 row-major*/,
+                       double *HDu /*uu,uv,vv*/, double *HDv)
+{
+    double u2 = u * u, v2 = v * v, r2 = u2 + v2, r4 = r2 * r2, r6 = r4 * r2;
+    double N = 1 + k->k1 * r2 + k->k2 * r4 + k->k3 * r6;
+    double N1 = k->k1 + 2 * k->k2 * r2 + 3 * k->k3 * r4, N2 = 2 * k->k2 + 6 * k->k3 * r2;
+    double Dn = 1 + k->k4 * r2 + k->k5 * r4 + k->k6 * r6;
+    double D1 = k->k4 + 2 * k->k5 * r2 + 3 * k->k6 * r4, D2 = 2 * k->k5 + 6 * k->k6 * r2;
+    double c = N / Dn;
+    double c1 = (N1 - c * D1) / Dn;                 /* dc/dr2 */
+    double c2 = (N2 - 2 * c1 * D1 - c * D2) / Dn;   /* d2c/dr2^2 */
+    D[0] = c * u + 2 * k->p1 * u * v + k->p2 * (r2 + 2 * u2) + k->s1 * r2 + k->s2 * r4;
+    D[1] = c * v + 2 * k->p2 * u * v + k->p1 * (r2 + 2 * v2) + k->s3 * r2 + k->s4 * r4;
+    JD[0] = c + 2 * u2 * c1 + 2 * k->p1 * v + 6 * k->p2 * u + 2 * k->s1 * u + 4 * k->s2 * r2 * u;
+    JD[1] = 2 * u * v * c1 + 2 * k->p1 * u + 2 * k->p2 * v + 2 * k->s1 * v + 4 * k->s2 * r2 * v;
+    JD[2] = 2 * u * v * c1 + 2 * k->p2 * v + 2 * k->p1 * u + 2 * k->s3 * u + 4 * k->s4 * r2 * u;
+    JD[3] = c + 2 * v2 * c1 + 2 * k->p2 * u + 6 * k->p1 * v + 2 * k->s3 * v + 4 * k->s4 * r2 * v;
+    HDu[0] = 6 * u * c1 + 4 * u2 * u * c2 + 6 * k->p2 + 2 * k->s1 + 4 * k->s2 * r2 + 8 * k->s2 * u2;
+    HDu[1] = 2 * v * c1 + 4 * u2 * v * c2 + 2 * k->p1 + 8 * k->s2 * u * v;
+    HDu[2] = 2 * u * c1 + 4 * u * v2 * c2 + 2 * k->p2 + 2 * k->s1 + 4 * k->s2 * r2 + 8 * k->s2 * v2;
+    HDv[0] = 2 * v * c1 + 4 * v * u2 * c2 + 2 * k->p1 + 2 * k->s3 + 4 * k->s4 * r2 + 8 * k->s4 * u2;
+    HDv[1] = 2 * u * c1 + 4 * v2 * u * c2 + 2 * k->p2 + 8 * k->s4 * u * v;
+    HDv[2] = 6 * v * c1 + 4 * v2 * v * c2 + 6 * k->p1 + 2 * k->s3 + 4 * k->s4 * r2 + 8 * k->s4 * v2;
+}
+
+/* Gradient (9) and Hessian (9x9, col-major) of one landmark term w.r.t.
+ * z = (rCNn, Theta, r_j), by the dense chain rule
+ *   h = K D(pi(q)),  q = R(Theta)^T (r - rCNn),
+ *   grad l = J^T e / s^2,  hess l = (-J^T J + sum_k e_k hess h_k) / s^2. */
+static int analytic_landmark(const double *eta, const double *rP, const double *yj,
+                             const orc_camera *cam, const coeffs *k, double sigma,
+                             double *val, double *g9, double *H81)
+{
+    double px[2];
+    int flag = orc_world_to_pixel(rP, eta, cam, px);
+    if (flag != 0) return flag;
+    double Rx[9], Ry[9], Rz[9], dRx[9], dRy[9], dRz[9], ddRx[9], ddRy[9], ddRz[9];
+    double sp = sin(eta[3]), cp = cos(eta[3]), st = sin(eta[4]), ct = cos(eta[4]);
+    double ss = sin(eta[5]), cs = cos(eta[5]);
+    orc_rotx(eta[3], Rx); orc_roty(eta[4], Ry); orc_rotz(eta[5], Rz);
+    memset(dRx, 0, sizeof dRx); memset(dRy, 0, sizeof dRy); memset(dRz, 0, sizeof dRz);
+    dRx[4] = -sp; dRx[7] = -cp; dRx[5] = cp; dRx[8] = -sp;
+    dRy[0] = -st; dRy[6] = ct; dRy[2] = -ct; dRy[8] = -st;
+    dRz[0] = -ss; dRz[3] = -cs; dRz[1] = cs; dRz[4] = -ss;
+    memset(ddRx, 0, sizeof ddRx); memset(ddRy, 0, sizeof ddRy); memset(ddRz, 0, sizeof ddRz);
+    ddRx[4] = -cp; ddRx[7] = sp; ddRx[5] = -sp; ddRx[8] = -cp;
+    ddRy[0] = -ct; ddRy[6] = -st; ddRy[2] = st; ddRy[8] = -ct;
+    ddRz[0] = -cs; ddRz[3] = ss; ddRz[1] = -ss; ddRz[4] = -cs;
+    const double *Xs[3] = {Rx, dRx, ddRx}, *Ys[3] = {Ry, dRy, ddRy}, *Zs[3] = {Rz, dRz, ddRz};
+    /* Rd[a][b][c] = Z^(c) Y^(b) X^(a) : derivative orders (phi, theta, psi) */
+    double R[9], dR[3][9], ddR[3][3][9], T[9];
+    mat3_mul(Zs[0], Ys[0], T); mat3_mul(T, Xs[0], R);
+    for (int a = 0; a < 3; ++a) {
+        int o[3] = {0, 0, 0}; o[a] = 1;
+        mat3_mul(Zs[o[2]], Ys[o[1]], T); mat3_mul(T, Xs[o[0]], dR[a]);
+        for (int b = 0; b < 3; ++b) {
+            int o2[3] = {0, 0, 0}; o2[a] += 1; o2[b] += 1;
+            mat3_mul(Zs[o2[2]], Ys[o2[1]], T); mat3_mul(T, Xs[o2[0]], ddR[a][b]);
+        }
+    }
+    double d[3], q[3];
+    for (int i = 0; i < 3; ++i) d[i] = rP[i] - eta[i];
+    mat3_tvec(R, d, q);
+    /* Jq: 3x9, columns (c, Theta, r) */
+    double Jq[3][9];
+    for (int m = 0; m < 3; ++m)
+        for (int i = 0; i < 3; ++i) { Jq[m][i] = -R[i + 3 * m]; Jq[m][6 + i] = R[i + 3 * m]; }
+    for (int a = 0; a < 3; ++a) {
+        double t[3]; mat3_tvec(dR[a], d, t);
+        for (int m = 0; m < 3; ++m) Jq[m][3 + a] = t[m];
+    }
+    /* Hq[m]: 9x9 second derivatives of q_m */
+    double Hq[3][9][9];
+    memset(Hq, 0, sizeof Hq);
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) {
+            double t[3]; mat3_tvec(ddR[a][b], d, t);
+            for (int m = 0; m < 3; ++m) Hq[m][3 + a][3 + b] = t[m];
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int m = 0; m < 3; ++m) {
+                double e = dR[a][i + 3 * m];           /* d q_m / d r_i d Theta_a */
+                Hq[m][3 + a][6 + i] = e;  Hq[m][6 + i][3 + a] = e;
+                Hq[m][3 + a][i] = -e;     Hq[m][i][3 + a] = -e;
+            }
+    }
+    /* (u,v) of q */
+    double z = q[2], u = q[0] / z, v = q[1] / z;
+    double Ja[2][3] = {{1 / z, 0, -u / z}, {0, 1 / z, -v / z}};
+    double Ha[2][3][3];
+    memset(Ha, 0, sizeof Ha);
+    Ha[0][0][2] = Ha[0][2][0] = -1 / (z * z); Ha[0][2][2] = 2 * u / (z * z);
+    Ha[1][1][2] = Ha[1][2][1] = -1 / (z * z); Ha[1][2][2] = 2 * v / (z * z);
+    double Dv[2], JD[4], HDu[3], HDv[3];
+    distort_d2(k, u, v, Dv, JD, HDu, HDv);
+    double f[2] = {k->fx, k->fy};
+    double Jp[2][2] = {{f[0] * JD[0], f[0] * JD[1]}, {f[1] * JD[2], f[1] * JD[3]}};
+    double Hp[2][2][2] = {{{f[0] * HDu[0], f[0] * HDu[1]}, {f[0] * HDu[1], f[0] * HDu[2]}},
+                          {{f[1] * HDv[0], f[1] * HDv[1]}, {f[1] * HDv[1], f[1] * HDv[2]}}};
+    /* g_k(q): Jg 2x3, Hg[k] 3x3 */
+    double Jg[2][3], Hg[2][3][3];
+    for (int kk = 0; kk < 2; ++kk)
+        for (int i = 0; i < 3; ++i) {
+            Jg[kk][i] = Jp[kk][0] * Ja[0][i] + Jp[kk][1] * Ja[1][i];
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) s += Ja[a][i] * Hp[kk][a][b] * Ja[b][j];
+                s += Jp[kk][0] * Ha[0][i][j] + Jp[kk][1] * Ha[1][i][j];
+                Hg[kk][i][j] = s;
+            }
+        }
+    /* h_k(z): J 2x9, Hh[k] 9x9 */
+    double J[2][9];
+    double Hh[2][9][9];
+    for (int kk = 0; kk < 2; ++kk)
+        for (int i = 0; i < 9; ++i) {
+            J[kk][i] = Jg[kk][0] * Jq[0][i] + Jg[kk][1] * Jq[1][i] + Jg[kk][2] * Jq[2][i];
+            for (int j = 0; j < 9; ++j) {
+                double s = 0;
+                for (int a = 0; a < 3; ++a) {
+                    for (int b = 0; b < 3; ++b) s += Jq[a][i] * Hg[kk][a][b] * Jq[b][j];
+                    s += Jg[kk][a] * Hq[a][i][j];
+                }
+                Hh[kk][i][j] = s;
+            }
+        }
+    double e[2] = {yj[0] - px[0], yj[1] - px[1]}, is2 = 1.0 / (sigma * sigma);
+    *val = -0.5 * (e[0] * e[0] + e[1] * e[1]) * is2 - log(2 * M_PI) - 2 * log(fabs(sigma));
+    for (int i = 0; i < 9; ++i) {
+        g9[i] = (J[0][i] * e[0] + J[1][i] * e[1]) * is2;
+        for (int j = 0; j < 9; ++j)
+            H81[i + 9 * j] = (-(J[0][i] * J[0][j] + J[1][i] * J[1][j]) + e[0] * Hh[0][i][j] + e[1] * Hh[1][i][j]) * is2;
+    }
+    return 0;
+}
+
+void orc_point_loglik_analytic(const double *x, int n, const double *y, const uint8_t *visible,
+                               const orc_camera *cam, double sigma,
+                               double *value, double *g, double *H, int32_t *code)
+{
+    int L = (n - 12) / 3;
+    coeffs k; select_coeffs(cam, &k);
+    if (g) memset(g, 0, sizeof(double) * (size_t)n);
+    if (H) memset(H, 0, sizeof(double) * (size_t)n * n);
+    double val = 0.0;
+    for (int l = 0; l < L; ++l) {
+        double v, g9[9], H81[81];
+        int idx[9];
+        for (int a = 0; a < 6; ++a) idx[a] = 6 + a;
+        for (int a = 0; a < 3; ++a) idx[6 + a] = 12 + 3 * l + a;
+        int flag;
+        if (!visible[l]) { double px[2]; flag = orc_world_to_pixel(x + 12 + 3 * l, x + 6, cam, px); if (code) code[l] = flag; continue; }
+        flag = analytic_landmark(x + 6, x + 12 + 3 * l, y + 2 * l, cam, &k, sigma, &v, g9, H81);
+        if (code) code[l] = flag;
+        if (flag != 0) continue;
+        val += v;
+        for (int a = 0; a < 9; ++a) {
+            if (g) g[idx[a]] += g9[a];
+            if (H) for (int b = 0; b < 9; ++b) H[idx[a] + (size_t)n * idx[b]] += H81[a + 9 * b];
+        }
+    }
+    if (value) *value = val;
+}
+
+/* ------------------------------------------------------------------ */
+/* Gaussian algebra                                                     */
+/* ------------------------------------------------------------------ */
+/* solve S^T z = b (S upper) in place: forward substitution */
+static void trsv_ut(const double *S, int n, int ld, double *b)
+{
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= S[k + (size_t)ld * i] * b[k];
+        b[i] = s / S[i + (size_t)ld * i];
+    }
+}
+/* solve S z = b (S upper) in place: back substitution */
+static void trsv_u(const double *S, int n, int ld, double *b)
+{
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= S[i + (size_t)ld * k] * b[k];
+        b[i] = s / S[i + (size_t)ld * i];
+    }
+}
+
+/* src/gaussian.hpp:30-74 */
+double orc_log_gaussian(const double *x, const double *mu, const double *S, int n, int ldS,
+                        double *g, double *H)
+{
+    double *z = (double *)malloc(sizeof(double) * (size_t)n);
+    double log_sum = 0.0, sq = 0.0;
+    for (int i = 0; i < n; ++i) { log_sum += log(fabs(S[i + (size_t)ldS * i])); z[i] = x[i] - mu[i]; }
+    trsv_ut(S, n, ldS, z);                                  /* :43 */
+    for (int i = 0; i < n; ++i) sq += z[i] * z[i];
+    double val = -0.5 * sq - (double)n / 2 * log(2 * M_PI) - log_sum;  /* :45 */
+    if (g) {                                                /* :55-56 */
+        for (int i = 0; i < n; ++i) g[i] = z[i];
+        trsv_u(S, n, ldS, g);
+        for (int i = 0; i < n; ++i) g[i] = -g[i];
+    }
+    if (H) {                                                /* :69-72 */
+        for (int c = 0; c < n; ++c) {
+            double *col = H + (size_t)n * c;
+            for (int i = 0; i < n; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+            trsv_ut(S, n, ldS, col);
+            trsv_u(S, n, ldS, col);
+            for (int i = 0; i < n; ++i) col[i] = -col[i];
+        }
+    }
+    free(z);
+    return val;
+}
+
+/* Unblocked Householder QR, reflector convention of Eigen's makeHouseholder /
+ * LAPACK dlarfg: beta = -sign(alpha) * norm (alpha >= 0 -> negative beta);
+ * a column whose tail is exactly zero is left untouched (tau = 0). */
+void orc_qr_upper(double *A, int rows, int cols, int lda)
+{
+    int steps = rows < cols ? rows : cols;
+    double *v = (double *)malloc(sizeof(double) * (size_t)rows);
+    for (int k = 0; k < steps; ++k) {
+        double *col = A + (size_t)lda * k;
+        double tail = 0.0;
+        for (int i = k + 1; i < rows; ++i) tail += col[i] * col[i];
+        double c0 = col[k], beta, tau;
+        if (tail <= 2.2250738585072014e-308) { beta = c0; tau = 0.0; }
+        else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0) beta = -beta;
+            for (int i = k + 1; i < rows; ++i) v[i] = col[i] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        if (tau != 0.0) {
+            for (int j = k + 1; j < cols; ++j) {
+                double *cj = A + (size_t)lda * j;
+                double w = cj[k];
+                for (int i = k + 1; i < rows; ++i) w += v[i] * cj[i];
+                w *= tau;
+                cj[k] -= w;
+                for (int i = k + 1; i < rows; ++i) cj[i] -= v[i] * w;
+            }
+        }
+        col[k] = beta;
+        for (int i = k + 1; i < rows; ++i) col[i] = 0.0;
+    }
+    for (int j = 0; j < cols; ++j)
+        for (int i = j + 1; i < rows; ++i) A[i + (size_t)lda * j] = 0.0;
+    free(v);
+}
+
+/* src/gaussian.hpp:117-127 */
+void orc_affine_sqrt(const double *S, int n, int ldS, const double *C, int m, int ldC,
+                     const double *SR, int ldSR, double *Syy, int ldSyy)
+{
+    int rows = n + m;
+    double *A = (double *)calloc((size_t)rows * m, sizeof(double));
+    for (int j = 0; j < m; ++j) {
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += S[i + (size_t)ldS * k] * C[j + (size_t)ldC * k];
+            A[i + (size_t)rows * j] = s;
+        }
+        for (int i = 0; i < m; ++i) A[n + i + (size_t)rows * j] = SR[i + (size_t)ldSR * j];
+    }
+    orc_qr_upper(A, rows, m, rows);
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < m; ++i) Syy[i + (size_t)ldSyy * j] = A[i + (size_t)rows * j];
+    free(A);
+}
+
+/* src/gaussian.cpp:19-36 */
+void orc_condition_on_marginal(const double *muyx, const double *Syx, int ny, int nx, int ld,
+                               const double *y, double *mux_out, double *Sx_out, int ldo)
+{
+    double *t = (double *)malloc(sizeof(double) * (size_t)ny);
+    for (int i = 0; i < ny; ++i) t[i] = y[i] - muyx[i];
+    trsv_ut(Syx, ny, ld, t);                                /* S1^T \ (y - muy) */
+    for (int i = 0; i < nx; ++i) {
+        double s = muyx[ny + i];
+        for (int k = 0; k < ny; ++k) s += Syx[k + (size_t)ld * (ny + i)] * t[k];  /* S2^T t */
+        mux_out[i] = s;
+    }
+    for (int j = 0; j < nx; ++j)
+        for (int i = 0; i < nx; ++i) Sx_out[i + (size_t)ldo * j] = Syx[(ny + i) + (size_t)ld * (ny + j)];
+    free(t);
+}
+
+/* src/gaussian.hpp:513-516 */
+void orc_iekf_post_sqrt(const double *Q, const double *v, int n, double *S_out)
+{
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) S_out[i + (size_t)n * j] = (1.0 / sqrt(v[i])) * Q[j + (size_t)n * i];
+    orc_qr_upper(S_out, n, n, n);
+}
+
+/* Cyclic Jacobi; ascending eigenvalues; uses the lower triangle of H. */
+void orc_sym_eig(const double *Hin, int n, double *Q, double *v)
+{
+    double *A = (double *)malloc(sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; ++j)
+        for (int i = j; i < n; ++i) {
+            A[i + (size_t)n * j] = Hin[i + (size_t)n * j];
+            A[j + (size_t)n * i] = Hin[i + (size_t)n * j];
+        }
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Q[i + (size_t)n * j] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int j = 0; j < n; ++j) {
+            diag += A[j + (size_t)n * j] * A[j + (size_t)n * j];
+            for (int i = j + 1; i < n; ++i) off += A[i + (size_t)n * j] * A[i + (size_t)n * j];
+        }
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p + (size_t)n * q];
+                if (apq == 0.0) continue;
+                double app = A[p + (size_t)n * p], aqq = A[q + (size_t)n * q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int kk = 0; kk < n; ++kk) {
+                    double akp = A[kk + (size_t)n * p], akq = A[kk + (size_t)n * q];
+                    A[kk + (size_t)n * p] = c * akp - s * akq;
+                    A[kk + (size_t)n * q] = s * akp + c * akq;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    double apk = A[p + (size_t)n * kk], aqk = A[q + (size_t)n * kk];
+                    A[p + (size_t)n * kk] = c * apk - s * aqk;
+                    A[q + (size_t)n * kk] = s * apk + c * aqk;
+                }
+                for (int kk = 0; kk < n; ++kk) {
+                    double qkp = Q[kk + (size_t)n * p], qkq = Q[kk + (size_t)n * q];
+                    Q[kk + (size_t)n * p] = c * qkp - s * qkq;
+                    Q[kk + (size_t)n * q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) v[i] = A[i + (size_t)n * i];
+    /* selection sort ascending */
+    for (int i = 0; i < n - 1; ++i) {
+        int m = i;
+        for (int j = i + 1; j < n; ++j) if (v[j] < v[m]) m = j;
+        if (m != i) {
+            double t = v[i]; v[i] = v[m]; v[m] = t;
+            for (int kk = 0; kk < n; ++kk) {
+                double tq = Q[kk + (size_t)n * i]; Q[kk + (size_t)n * i] = Q[kk + (size_t)n * m]; Q[kk + (size_t)n * m] = tq;
+            }
+        }
+    }
+    free(A);
+}
+
+static double vnorm(const double *a, int n) { double s = 0; for (int i = 0; i < n; ++i) s += a[i] * a[i]; return sqrt(s); }
+
+/* src/fmin.cpp:40-131 */
+int orc_trs(const double *Q, const double *v, const double *g, int n, double D, double *p)
+{
+    const double eps = 2.220446049250313e-16, sqrteps = sqrt(eps);
+    const int maxIterations = 20;
+    double l1 = v[0];
+    double *a = (double *)malloc(sizeof(double) * (size_t)n);
+    double *vlam = (double *)malloc(sizeof(double) * (size_t)n);
+    double *t = (double *)malloc(sizeof(double) * (size_t)n);
+    int ret = 0;
+    for (int j = 0; j < n; ++j) { double s = 0; for (int i = 0; i < n; ++i) s += Q[i + (size_t)n * j] * g[i]; a[j] = s; }
+    double lam = (l1 < 0) ? 1.01 * fabs(l1) : 0;
+    for (int i = 0; i < n; ++i) vlam[i] = v[i] + lam;
+#define ORC_P_FROM(vl) do { for (int i_ = 0; i_ < n; ++i_) t[i_] = a[i_] / (vl)[i_]; \
+        for (int r_ = 0; r_ < n; ++r_) { double s_ = 0; for (int c_ = 0; c_ < n; ++c_) s_ += Q[r_ + (size_t)n * c_] * t[c_]; p[r_] = -s_; } } while (0)
+    ORC_P_FROM(vlam);
+    int hard = fabs(a[0]) < eps && l1 < 0;
+    double pn = vnorm(p, n);
+    if (l1 < 0 || pn > D || fabs(lam * (pn - D)) > sqrteps) {
+        if (hard) {
+            double *pvec = (double *)calloc((size_t)n, sizeof(double));
+            double ssq = 0;
+            for (int i = 0; i < n; ++i)
+                if (fabs(v[i] - l1) > sqrteps) {
+                    double sc = a[i] / (v[i] - l1);
+                    ssq += sc * sc;
+                    for (int r = 0; r < n; ++r) pvec[r] += Q[r + (size_t)n * i] * sc;
+                }
+            double tt = sqrt(D * D - ssq);
+            for (int r = 0; r < n; ++r) p[r] = tt * Q[r] - pvec[r];
+            double pg = 0, quad = 0;
+            for (int r = 0; r < n; ++r) pg += p[r] * g[r];
+            for (int j = 0; j < n; ++j) { double s = 0; for (int i = 0; i < n; ++i) s += Q[i + (size_t)n * j] * p[i]; quad += s * v[j] * s; }
+            if (pg + 0.5 * quad > 0.0)
+                for (int r = 0; r < n; ++r) p[r] = -tt * Q[r] - pvec[r];
+            free(pvec);
+        } else {
+            int k;
+            for (k = 0; k < maxIterations; ++k) {
+                double ppn2 = 0, dpp = 0;
+                for (int i = 0; i < n; ++i) {
+                    double pp = -a[i] / vlam[i], dp = a[i] / (vlam[i] * vlam[i]);
+                    ppn2 += pp * pp; dpp += dp * pp;
+                }
+                double ppn = sqrt(ppn2);
+                double ff = 1 / D - 1 / ppn;
+                double gg = dpp / (ppn * ppn * ppn);
+                double lo = fmax(0.0, -l1) + sqrteps * fmax(0.0, -l1);
+                lam = fmax(lo, lam - ff / gg);
+                for (int i = 0; i < n; ++i) vlam[i] = v[i] + lam;
+                if (fabs(ff) < sqrteps) break;
+            }
+            ORC_P_FROM(vlam);
+            if (k >= maxIterations) ret = 1;
+        }
+    }
+#undef ORC_P_FROM
+    free(a); free(vlam); free(t);
+    return ret;
+}
+
+/* CostJointDensity, src/gaussian.hpp:455-466, with the prior Hessian cached
+ * (it does not depend on x; the reference recomputes it, :459). */
+typedef struct {
+    int n; const double *mu, *S, *y; const uint8_t *vis; const orc_camera *cam; double sigma;
+    double *Hprior; int evals;
+} cost_ctx;
+static double cost_eval(cost_ctx *c, const double *x, double *g, double *H)
+{
+    int n = c->n;
+    double *gp = (double *)malloc(sizeof(double) * (size_t)n);
+    double lp;
+    if (!c->Hprior) {
+        c->Hprior = (double *)malloc(sizeof(double) * (size_t)n * n);
+        lp = orc_log_gaussian(x, c->mu, c->S, n, n, gp, c->Hprior);
+    } else lp = orc_log_gaussian(x, c->mu, c->S, n, n, gp, NULL);
+    double ll;
+    orc_point_loglik_analytic(x, n, c->y, c->vis, c->cam, c->sigma, &ll, g, H, NULL);
+    for (int i = 0; i < n; ++i) g[i] = -(gp[i] + g[i]);
+    for (size_t i = 0; i < (size_t)n * n; ++i) H[i] = -(c->Hprior[i] + H[i]);
+    free(gp);
+    c->evals++;
+    return -(lp + ll);
+}
+
+/* src/gaussian.hpp:469-532 driving src/fmin.hpp:19-107 */
+int orc_measurement_update_iekf(const double *mu, const double *S, int n,
+                                const double *y, const uint8_t *visible,
+                                const orc_camera *cam, double sigma,
+                                double *mu_post, double *S_post, int *iters, int *cost_evals)
+{
+    size_t nn = (size_t)n * n;
+    cost_ctx c = {n, mu, S, y, visible, cam, sigma, NULL, 0};
+    double *x = mu_post;
+    memcpy(x, mu, sizeof(double) * (size_t)n);              /* gaussian.hpp:494 */
+    double *g = (double *)malloc(sizeof(double) * n), *gn = (double *)malloc(sizeof(double) * n);
+    double *xn = (double *)malloc(sizeof(double) * n), *p = (double *)malloc(sizeof(double) * n);
+    double *H = (double *)malloc(sizeof(double) * nn), *Hn = (double *)malloc(sizeof(double) * nn);
+    double *Q = (double *)malloc(sizeof(double) * nn), *v = (double *)malloc(sizeof(double) * n);
+    double f = cost_eval(&c, x, g, H);                      /* fmin.hpp:39 */
+    orc_sym_eig(H, n, Q, v);
+    double Delta = 1e0;
+    int ret = 1, i;
+    for (i = 0; i < 50; ++i) {
+        orc_trs(Q, v, g, n, Delta, p);
+        double pg = 0; for (int k = 0; k < n; ++k) pg += p[k] * g[k];
+        double LambdaSq = -pg;
+        if (fabs(LambdaSq) < 2 * 2.220446049250313e-16) { ret = 0; break; }
+        for (int k = 0; k < n; ++k) xn[k] = x[k] + p[k];
+        double fn = cost_eval(&c, xn, gn, Hn);
+        double pHp = 0;
+        for (int r = 0; r < n; ++r) { double s = 0; for (int cc = 0; cc < n; ++cc) s += H[r + (size_t)n * cc] * p[cc]; pHp += p[r] * s; }
+        double dm = -pg - 0.5 * pHp;
+        double rho = (f - fn) / dm;
+        double pn = vnorm(p, n);
+        if (rho < 0.1) Delta = 0.25 * pn;
+        else if (rho > 0.75 && pn > 0.8 * Delta) Delta = 2.0 * Delta;
+        if (rho >= 0.001) {
+            memcpy(x, xn, sizeof(double) * n); f = fn;
+            memcpy(g, gn, sizeof(double) * n); memcpy(H, Hn, sizeof(double) * nn);
+            orc_sym_eig(H, n, Q, v);
+        }
+    }
+    orc_iekf_post_sqrt(Q, v, n, S_post);
+    if (iters) *iters = i;
+    if (cost_evals) *cost_evals = c.evals;
+    free(g); free(gn); free(xn); free(p); free(H); free(Hn); free(Q); free(v); free(c.Hprior);
+    return ret;
+}
+
+/* ------------------------------------------------------------------ */
+/* image front end                                                      */
+/* ------------------------------------------------------------------ */
+/*
+ * The reference calls cv::ORB with HARRIS_SCORE (src/imagefeatures.cpp:71-96);
+ * the corner arithmetic itself lives in OpenCV, which is not available, and no
+ * reference test covers it: keypoint parity is UNPINNED by the reference.
+ * This oracle defines the contract the GPU must match bit for bit:
+ *
+ *   Ix, Iy   3x3 Sobel on the u8 image, exact int32
+ *   a,b,c    sums of Ix^2, Iy^2, IxIy over a block_size^2 window, exact int32
+ *   scale    s = 1/(4*block_size*255), s2 = s*s, s4 = s2*s2 (float32)
+ *   Harris   ((fa*fb - fc*fc) - k*((fa+fb)*(fa+fb))) * s4      (float32, each
+ *            operation rounded once, no fused multiply-add)
+ *   Shi-T.   (((fa+fb)*0.5f) - sqrtf(d*d + fc*fc)) * s2, d = (fa-fb)*0.5f
+ *   valid    pixels at least 1+block_size/2 from every edge; 0 elsewhere
+ *   NMS      3x3: strictly greater than the 4 neighbours that precede in
+ *            raster order, greater-or-equal than the 4 that follow
+ *   keep     response > threshold, border <= x < w-border, same for y
+ *   order    score descending, then y, then x ascending; first max_features
+ */
+static void structure_tensor(const uint8_t *g, int w, int h, int stride, int bs,
+                             int32_t *A, int32_t *B, int32_t *C)
+{
+    size_t npx = (size_t)w * h;
+    int16_t *Ix = (int16_t *)calloc(npx, sizeof(int16_t)), *Iy = (int16_t *)calloc(npx, sizeof(int16_t));
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x) {
+            const uint8_t *r0 = g + (size_t)stride * (y - 1), *r1 = g + (size_t)stride * y, *r2 = g + (size_t)stride * (y + 1);
+            Ix[x + (size_t)w * y] = (int16_t)((r0[x + 1] - r0[x - 1]) + 2 * (r1[x + 1] - r1[x - 1]) + (r2[x + 1] - r2[x - 1]));
+            Iy[x + (size_t)w * y] = (int16_t)((r2[x - 1] - r0[x - 1]) + 2 * (r2[x] - r0[x]) + (r2[x + 1] - r0[x + 1]));
+        }
+    int hb = bs / 2, R = 1 + hb;
+    memset(A, 0, npx * sizeof(int32_t)); memset(B, 0, npx * sizeof(int32_t)); memset(C, 0, npx * sizeof(int32_t));
+    for (int y = R; y < h - R; ++y)
+        for (int x = R; x < w - R; ++x) {
+            int32_t a = 0, b = 0, c = 0;
+            for (int dy = -hb; dy <= hb; ++dy)
+                for (int dx = -hb; dx <= hb; ++dx) {
+                    int32_t ix = Ix[(x + dx) + (size_t)w * (y + dy)], iy = Iy[(x + dx) + (size_t)w * (y + dy)];
+                    a += ix * ix; b += iy * iy; c += ix * iy;
+                }
+            A[x + (size_t)w * y] = a; B[x + (size_t)w * y] = b; C[x + (size_t)w * y] = c;
+        }
+    free(Ix); free(Iy);
+}
+
+void orc_corner_response(const uint8_t *gray, int w, int h, int stride,
+                         const orc_corner_params *p, float *harris, float *shi)
+{
+    size_t npx = (size_t)w * h;
+    int32_t *A = (int32_t *)malloc(npx * 4), *B = (int32_t *)malloc(npx * 4), *C = (int32_t *)malloc(npx * 4);
+    structure_tensor(gray, w, h, stride, p->block_size, A, B, C);
+    volatile float s = 1.0f / (4.0f * (float)p->block_size * 255.0f);
+    volatile float s2 = s * s;
+    volatile float s4 = s2 * s2;
+    int R = 1 + p->block_size / 2;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t i = x + (size_t)w * y;
+            if (x < R || y < R || x >= w - R || y >= h - R) {
+                if (harris) harris[i] = 0.0f;
+                if (shi) shi[i] = 0.0f;
+                continue;
+            }
+            volatile float fa = (float)A[i], fb = (float)B[i], fc = (float)C[i];
+            volatile float t1 = fa * fb, t2 = fc * fc, t3 = t1 - t2;
+            volatile float t4 = fa + fb, t5 = t4 * t4, t6 = p->harris_k * t5, t7 = t3 - t6;
+            if (harris) harris[i] = t7 * s4;
+            volatile float m = t4 * 0.5f, d = (fa - fb) * 0.5f, dd = d * d, disc = dd + t2;
+            volatile float root = sqrtf(disc), lam = m - root;
+            if (shi) shi[i] = lam * s2;
+        }
+    free(A); free(B); free(C);
+}
+
+static int feat_cmp(const void *pa, const void *pb)
+{
+    const orc_feature *a = (const orc_feature *)pa, *b = (const orc_feature *)pb;
+    if (a->score != b->score) return a->score > b->score ? -1 : 1;
+    if (a->y != b->y) return a->y < b->y ? -1 : 1;
+    return a->x < b->x ? -1 : (a->x > b->x);
+}
+
+int orc_corner_detect(const uint8_t *gray, int w, int h, int stride,
+                      const orc_corner_params *p, int which, orc_feature *out, int cap)
+{
+    size_t npx = (size_t)w * h;
+    float *resp = (float *)malloc(npx * sizeof(float));
+    orc_corner_response(gray, w, h, stride, p, which == 0 ? resp : NULL, which == 0 ? NULL : resp);
+    float thr = which == 0 ? p->harris_thresh : p->shi_thresh;
+    int bd = p->border;
+    size_t cnt = 0, capc = 1024;
+    orc_feature *cand = (orc_feature *)malloc(capc * sizeof(orc_feature));
+    for (int y = bd; y < h - bd; ++y)
+        for (int x = bd; x < w - bd; ++x) {
+            float r = resp[x + (size_t)w * y];
+            if (!(r > thr)) continue;
+            int ok = 1;
+            for (int dy = -1; dy <= 1 && ok; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (!dx && !dy) continue;
+                    float nb = resp[(x + dx) + (size_t)w * (y + dy)];
+                    int before = dy < 0 || (dy == 0 && dx < 0);
+                    if (before ? !(r > nb) : !(r >= nb)) { ok = 0; break; }
+                }
+            if (!ok) continue;
+            if (cnt == capc) { capc *= 2; cand = (orc_feature *)realloc(cand, capc * sizeof(orc_feature)); }
+            cand[cnt].x = x; cand[cnt].y = y; cand[cnt].score = r; ++cnt;
+        }
+    qsort(cand, cnt, sizeof(orc_feature), feat_cmp);
+    int lim = p->max_features < cap ? p->max_features : cap;
+    int nout = (int)(cnt < (size_t)lim ? cnt : (size_t)lim);
+    memcpy(out, cand, (size_t)nout * sizeof(orc_feature));
+    free(cand); free(resp);
+    return nout;
+}
