@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the point-landmark hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path over one batch of synthetic input held
+in HBM: `--instances` independent filter instances per GPU, each a
+point-landmark update of L=150 landmarks (state dim n=462): log-likelihood +
+gradient + exact Hessian in fp64, one batched kernel launch.  A *landmark
+update* = evaluating (l_j, grad l_j, hess l_j) for one landmark and accumulating
+it into the dense g/H; value = landmark updates per second over all ranks.
+With --gpus N > 1 (launched by torch.distributed.run) every rank owns its own
+instances (weak scaling, no data-path collective).
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      dominant kernel (point_loglik) against the HBM roof
+  cpu_baseline  the CPU oracle timed on this host (N=1 only), reference-faithful
+                autodiff pass structure, single thread
+  corner        the front-end leg: 1080p frames/s with its own roofline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L_LANDMARKS = 150
+N_STATE = 12 + 3 * L_LANDMARKS
+SIGMA = 7.0
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec
+
+
+def loglik_algorithmic_bytes(n, L):
+    """Bytes one call must move: dense H write + g write + x read + per-landmark
+    (y 16 B + visible 1 B) + camera struct/sigma/value (168 B)."""
+    return 8 * n * n + 8 * n + 8 * n + 17 * L + 168
+
+
+def corner_algorithmic_bytes(w, h, k):
+    """One u8 frame read + 12-byte keypoint records written."""
+    return w * h + 12 * k
+
+
+def build_scenes(count, seed0):
+    from visualslam_amd import synthetic as syn
+    cam = syn.read_camera_xml()
+    scs = [syn.Scene(L_LANDMARKS, seed0 + i, cam=cam, dense_S=False) for i in range(count)]
+    return (np.stack([s.x for s in scs]), np.stack([s.y for s in scs]), np.stack([s.visible for s in scs]))
+
+
+def cpu_baseline(x, y, vis, budget_s=12.0):
+    """Times the CPU oracle's reference-faithful path (n(n+1)/2 second-order dual
+    passes per Hessian, src/model.cpp:427-437) on a bounded sample of the same
+    workload and extrapolates to whole Hessians."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import synthetic as syn
+    c = syn.read_camera_xml()
+    cam = orc.make_camera(c["K"][0, 0], c["K"][1, 1], c["K"][0, 2], c["K"][1, 2], c["dist"], c["flag"],
+                          c["width"], c["height"])
+    n = x.shape[1]
+    full_passes = n * (n + 1) // 2
+    t0 = time.perf_counter()
+    _, _, _, p = orc.point_loglik_autodiff(x[0], y[0], vis[0], cam, SIGMA, 0, 1)
+    dt = time.perf_counter() - t0
+    rate = p / dt
+    rows = 1
+    want = rate * budget_s
+    acc = 0
+    while rows < n and acc < want:
+        acc += n - rows
+        rows += 1
+    t0 = time.perf_counter()
+    _, _, _, passes = orc.point_loglik_autodiff(x[0], y[0], vis[0], cam, SIGMA, 1, rows)
+    dt = time.perf_counter() - t0
+    sec_per_hessian = dt / passes * full_passes
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 1.0:
+        orc.point_loglik_analytic(x[reps % x.shape[0]], y[reps % x.shape[0]], vis[reps % x.shape[0]], cam, SIGMA)
+        reps += 1
+    analytic = reps * L_LANDMARKS / (time.perf_counter() - t0)
+    return {
+        "value": L_LANDMARKS / sec_per_hessian, "unit": "landmark updates/s", "cores": 1, "kind": "port",
+        "sample": "oracle autodiff-faithful path on instance 0: %d of %d dual2nd likelihood passes (%.1f s), "
+                  "extrapolated to a whole Hessian" % (passes, full_passes, dt),
+        "seconds_per_cost_evaluation": sec_per_hessian,
+        "analytic_port_updates_per_s": analytic,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--instances", type=int, default=512, help="filter instances per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step (corner leg)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-corner", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from visualslam_amd import api, synthetic as syn
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; libvslam_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B, n, L = args.instances, N_STATE, L_LANDMARKS
+    uniq = min(B, 32)
+    xs, ys, vs = build_scenes(uniq, 9000 + 4096 * rank)
+    reps = (B + uniq - 1) // uniq
+    rng = np.random.default_rng(77 + rank)
+    x_np = np.tile(xs, (reps, 1))[:B] + 1e-3 * rng.standard_normal((B, n))   # distinct instances
+    x = torch.tensor(x_np, device=dev)
+    y = torch.tensor(np.tile(ys, (reps, 1))[:B], device=dev)
+    vis = torch.tensor(np.tile(vs, (reps, 1))[:B], device=dev)
+    val = torch.empty(B, dtype=torch.float64, device=dev)
+    g = torch.empty((B, n), dtype=torch.float64, device=dev)
+    H = torch.empty((B, n, n), dtype=torch.float64, device=dev)
+    code = torch.empty((B, L), dtype=torch.int32, device=dev)
+
+    stream = torch.cuda.current_stream()
+    ctx = api.Context(local_rank, stream=stream.cuda_stream)
+    cam = api.camera_from_xml(syn.CAMERA_XML)
+
+    def step():
+        api.point_loglik_batch_dev(ctx, cam, n, x, y, vis, SIGMA, val, g, H, code)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-instance latency of the same update (launch-latency bound; reported, not the headline)
+    x1, y1, v1 = x[:1], y[:1], vis[:1]
+    for _ in range(5):
+        api.point_loglik_batch_dev(ctx, cam, n, x1, y1, v1, SIGMA, val[:1], g[:1], H[:1], code[:1])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(200):
+        api.point_loglik_batch_dev(ctx, cam, n, x1, y1, v1, SIGMA, val[:1], g[:1], H[:1], code[:1])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    single_us = e0.elapsed_time(e1) / 200 * 1e3
+
+    corner = None
+    if not args.no_corner:
+        try:
+            from bench_corner import run_corner_leg
+            corner = run_corner_leg(args, ctx, dev, stream, rank, world, barrier)
+        except ImportError:
+            corner = None
+
+    if rank == 0:
+        units = B * L * args.steps * world
+        alg = loglik_algorithmic_bytes(n, L) * B
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_point_loglik.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "landmark Jacobian updates/s", "value": units / elapsed, "unit": "landmark updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3 x%d: %d independent point-landmark updates per GPU per step, L=150 landmarks, "
+                                   "n=462 states, log-lik + gradient + exact Hessian (BASELINE configs[2] batched as configs[4])"
+                                   % (B, B),
+                       "instances_per_gpu": B, "landmarks": L, "state_dim": n, "sigma_px": SIGMA,
+                       "parallelism": "replicated instances, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "point_loglik_kernel<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+            "single_instance_latency_us": single_us,
+            "single_instance_updates_per_s": L / (single_us * 1e-6),
+        }
+        if corner is not None:
+            out["corner"] = corner
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x_np, np.tile(ys, (reps, 1))[:B], np.tile(vs, (reps, 1))[:B])
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,248 @@
+"""Thin Python surface over the C ABI: numpy arrays go through the host-pointer
+entry points, torch CUDA tensors through the device-pointer (_dev) ones.
+
+Matrices are column-major float64 (numpy order='F'), the layout of
+Eigen::MatrixXd in the reference.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Camera, CornerParams, VslamError, check  # noqa: F401
+
+FEATURE_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("score", np.float32)])
+LAYOUT_COMPAT, LAYOUT_STRICT = 0, 1
+HARRIS, SHI_TOMASI = 0, 1
+
+
+class Context:
+    """One device context (one HIP stream).  stream: a raw hipStream_t handle
+    (e.g. torch.cuda.current_stream().cuda_stream) to borrow, or None to own one."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.lib()
+        self.ptr = C.c_void_p()
+        if stream is None:
+            st = self._L.vslam_ctx_create(device, C.byref(self.ptr))
+        else:
+            st = self._L.vslam_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(self.ptr))
+        if st != 0:
+            raise VslamError("cannot create a context on device %d: %s (status %d); libvslam_hip needs a gfx950 GPU"
+                             % (device, self._L.vslam_status_string(st).decode(), st))
+        self.device = device
+
+    def synchronize(self):
+        check(self._L.vslam_ctx_synchronize(self.ptr), self.ptr)
+
+    def close(self):
+        if self.ptr:
+            self._L.vslam_ctx_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def camera_from_xml(path):
+    cam = Camera()
+    check(_lib.lib().vslam_camera_from_xml(str(path).encode(), C.byref(cam)))
+    return cam
+
+
+def corner_params(block_size=7, border=None, max_features=10000, harris_k=0.04,
+                  harris_thresh=1e-4, shi_thresh=1e-3):
+    p = CornerParams()
+    p.block_size = block_size
+    p.border = (block_size // 2 + 2) if border is None else border
+    p.max_features = max_features
+    p.harris_k, p.harris_thresh, p.shi_thresh = harris_k, harris_thresh, shi_thresh
+    return p
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _F(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _tp(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ host-pointer calls
+def project(ctx, cam, x, j0=0, L=None):
+    x = _f64(x)
+    n = x.size
+    L = (n - 12) // 3 - j0 if L is None else L
+    px = np.zeros(2 * L)
+    code = np.zeros(L, dtype=np.int32)
+    check(ctx._L.vslam_project(ctx.ptr, C.byref(cam), _p(x), n, j0, L, _p(px), _p(code)), ctx.ptr)
+    return px, code
+
+
+def bundle_measure(ctx, cam, x, layout=LAYOUT_COMPAT, want_SR=True, want_C=True):
+    x = _f64(x)
+    n = x.size
+    L = (n - 12) // 3
+    h = np.zeros(2 * L)
+    SR = np.zeros((2 * L, 2 * L), order="F") if want_SR else None
+    Cm = np.zeros((2 * L, n), order="F") if want_C else None
+    code = np.zeros(L, dtype=np.int32)
+    check(ctx._L.vslam_bundle_measure(ctx.ptr, C.byref(cam), _p(x), n, layout, _p(h), _p(SR), _p(Cm), _p(code)), ctx.ptr)
+    return h, SR, Cm, code
+
+
+def single_measure(ctx, cam, j, x, layout=LAYOUT_COMPAT, want_SR=True, want_J=True):
+    x = _f64(x)
+    n = x.size
+    h = np.zeros(2)
+    SR = np.zeros((2, 2), order="F") if want_SR else None
+    J = np.zeros((2, n), order="F") if want_J else None
+    code = np.zeros(1, dtype=np.int32)
+    check(ctx._L.vslam_single_measure(ctx.ptr, C.byref(cam), j, _p(x), n, layout, _p(h), _p(SR), _p(J), _p(code)), ctx.ptr)
+    return int(code[0]), h, SR, J
+
+
+def point_loglik(ctx, cam, x, y, visible, sigma, want_g=True, want_H=True, ldH=None):
+    x, y = _f64(x), _f64(y)
+    n = x.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    val = np.zeros(1)
+    g = np.zeros(n) if (want_g or want_H) else None
+    ld = n if ldH is None else ldH
+    H = np.zeros((ld, n), order="F") if want_H else None
+    code = np.zeros((n - 12) // 3, dtype=np.int32)
+    check(ctx._L.vslam_point_loglik(ctx.ptr, C.byref(cam), _p(x), n, _p(y), _p(vis), float(sigma),
+                                    _p(val), _p(g), _p(H), ld, _p(code)), ctx.ptr)
+    return float(val[0]), g, H, code
+
+
+def log_gaussian(ctx, x, mu, S, want_g=True, want_H=True):
+    x, mu, S = _f64(x), _f64(mu), _F(S)
+    n = x.size
+    val = np.zeros(1)
+    g = np.zeros(n) if want_g or want_H else None
+    H = np.zeros((n, n), order="F") if want_H else None
+    check(ctx._L.vslam_log_gaussian(ctx.ptr, _p(x), _p(mu), _p(S), n, S.shape[0], _p(val), _p(g), _p(H)), ctx.ptr)
+    return float(val[0]), g, H
+
+
+def qr_upper(ctx, A):
+    A = np.array(A, dtype=np.float64, order="F", copy=True)
+    check(ctx._L.vslam_qr_upper(ctx.ptr, _p(A), A.shape[0], A.shape[1], A.shape[0]), ctx.ptr)
+    return A
+
+
+def affine_sqrt(ctx, S, Cm, SR):
+    S, Cm, SR = _F(S), _F(Cm), _F(SR)
+    n, m = S.shape[0], Cm.shape[0]
+    Syy = np.zeros((m, m), order="F")
+    check(ctx._L.vslam_affine_sqrt(ctx.ptr, _p(S), n, n, _p(Cm), m, m, _p(SR), m, _p(Syy), m), ctx.ptr)
+    return Syy
+
+
+def affine_bundle(ctx, cam, mux, Sxx, layout=LAYOUT_COMPAT):
+    mux, Sxx = _f64(mux), _F(Sxx)
+    n = mux.size
+    L = (n - 12) // 3
+    muy = np.zeros(2 * L)
+    Syy = np.zeros((2 * L, 2 * L), order="F")
+    code = np.zeros(L, dtype=np.int32)
+    check(ctx._L.vslam_affine_bundle(ctx.ptr, C.byref(cam), _p(mux), _p(Sxx), n, n, layout,
+                                     _p(muy), _p(Syy), 2 * L, _p(code)), ctx.ptr)
+    return muy, Syy, code
+
+
+def iekf_post_sqrt(ctx, Q, v):
+    Q, v = _F(Q), _f64(v)
+    n = v.size
+    S = np.zeros((n, n), order="F")
+    check(ctx._L.vslam_iekf_post_sqrt(ctx.ptr, _p(Q), _p(v), n, _p(S)), ctx.ptr)
+    return S
+
+
+def condition_on_marginal(ctx, muyx, Syx, y):
+    muyx, Syx, y = _f64(muyx), _F(Syx), _f64(y)
+    ny = y.size
+    nx = muyx.size - ny
+    mu = np.zeros(nx)
+    Sx = np.zeros((nx, nx), order="F")
+    check(ctx._L.vslam_condition_on_marginal(ctx.ptr, _p(muyx), _p(Syx), ny, nx, ny + nx, _p(y), _p(mu), _p(Sx), nx), ctx.ptr)
+    return mu, Sx
+
+
+def cost_joint_density(ctx, cam, x, mu, S, y, visible, sigma):
+    x, mu, S, y = _f64(x), _f64(mu), _F(S), _f64(y)
+    n = x.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    val = np.zeros(1)
+    g = np.zeros(n)
+    H = np.zeros((n, n), order="F")
+    check(ctx._L.vslam_cost_joint_density(ctx.ptr, C.byref(cam), _p(x), _p(mu), _p(S), n, n, _p(y), _p(vis),
+                                          float(sigma), _p(val), _p(g), _p(H)), ctx.ptr)
+    return float(val[0]), g, H
+
+
+def measurement_update_iekf(ctx, cam, mu, S, y, visible, sigma):
+    mu, S, y = _f64(mu), _F(S), _f64(y)
+    n = mu.size
+    vis = np.ascontiguousarray(visible, dtype=np.uint8)
+    mup = np.zeros(n)
+    Sp = np.zeros((n, n), order="F")
+    info = np.zeros(3, dtype=np.int32)
+    check(ctx._L.vslam_measurement_update_iekf(ctx.ptr, C.byref(cam), _p(mu), _p(S), n, n, _p(y), _p(vis), float(sigma),
+                                               _p(mup), _p(Sp), n, C.c_void_p(info.ctypes.data),
+                                               C.c_void_p(info.ctypes.data + 4), C.c_void_p(info.ctypes.data + 8)), ctx.ptr)
+    return int(info[0]), mup, Sp, int(info[1]), int(info[2])
+
+
+def corner_detect(ctx, gray, params, detector=HARRIS, cap=None):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    cap = params.max_features if cap is None else cap
+    out = np.zeros(cap, dtype=FEATURE_DTYPE)
+    cnt = np.zeros(1, dtype=np.int32)
+    check(ctx._L.vslam_corner_detect(ctx.ptr, _p(gray), w, h, w, C.byref(params), detector, _p(out), cap, _p(cnt)), ctx.ptr)
+    return out[:int(cnt[0])].copy()
+
+
+def corner_response(ctx, gray, params):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    har = np.zeros((h, w), dtype=np.float32)
+    shi = np.zeros((h, w), dtype=np.float32)
+    check(ctx._L.vslam_corner_response(ctx.ptr, _p(gray), w, h, w, C.byref(params), _p(har), _p(shi)), ctx.ptr)
+    return har, shi
+
+
+# ------------------------------------------------------------------ device-pointer calls (torch tensors)
+def point_loglik_batch_dev(ctx, cam, n, x, y, visible, sigma, value, g=None, H=None, code=None, ldH=None):
+    """x (B,n) f64, y (B,2L) f64, visible (B,L) u8, value (B,) f64, g (B,n) f64,
+    H (B,n,ldH) f64 holding each instance column-major, code (B,L) i32: torch
+    CUDA tensors, contiguous.  Queued on the context's stream, not synchronised."""
+    B = x.shape[0]
+    L = (n - 12) // 3
+    ld = n if ldH is None else ldH
+    check(ctx._L.vslam_point_loglik_batch_dev(
+        ctx.ptr, C.byref(cam), B, n, _tp(x), x.stride(0), _tp(y), y.stride(0), _tp(visible), visible.stride(0),
+        float(sigma), _tp(value), _tp(g), 0 if g is None else g.stride(0),
+        _tp(H), ld, 0 if H is None else H.stride(0), _tp(code)), ctx.ptr)
+
+
+def qr_upper_batch_dev(ctx, A, rows, cols, lda, batch, stride):
+    check(ctx._L.vslam_qr_upper_batch_dev(ctx.ptr, _tp(A), rows, cols, lda, stride, batch), ctx.ptr)
+
+
+def corner_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, params, detector, out, cap, count):
+    check(ctx._L.vslam_corner_detect_batch_dev(ctx.ptr, _tp(gray), w, h, stride, stride_frame, frames,
+                                               C.byref(params), detector, _tp(out), cap, _tp(count)), ctx.ptr)

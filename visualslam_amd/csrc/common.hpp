@@ -1,0 +1,79 @@
+// Shared host-side plumbing of libvslam_hip: context, error reporting,
+// device workspace.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vslam_hip.h"
+
+struct vslam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void *ws = nullptr;          // device workspace, grown on demand
+    size_t ws_bytes = 0;
+    void *pinned = nullptr;      // small pinned host staging buffer
+    size_t pinned_bytes = 0;
+    char err[512] = {0};
+};
+
+namespace vslam {
+
+inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return s;
+}
+
+#define VSLAM_HIP_TRY(ctx, expr)                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return vslam::fail((ctx), VSLAM_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,      \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define VSLAM_TRY(expr)                         \
+    do {                                        \
+        vslam_status s_ = (expr);               \
+        if (s_ != VSLAM_OK) return s_;          \
+    } while (0)
+
+// Ensures the context workspace holds at least `bytes`; contents are not kept
+// across a growth.  Synchronises the stream before freeing the old block.
+vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes);
+
+// Carves 256-byte aligned sub-buffers out of the workspace.
+struct Arena {
+    char *base;
+    size_t off = 0;
+    explicit Arena(void *p) : base(static_cast<char *>(p)) {}
+    static size_t pad(size_t b) { return (b + 255) & ~size_t(255); }
+    template <class T> T *take(size_t count)
+    {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += pad(count * sizeof(T));
+        return p;
+    }
+};
+
+// Camera constants resolved on the host (coefficient gating of the reference's
+// src/cameraModel.hpp:114-148) and passed to kernels by value.
+struct CamK {
+    double fx, fy, cx, cy;
+    double k1, k2, k3, k4, k5, k6, p1, p2, s1, s2, s3, s4;
+    double cos_half_fov, wmax, hmax;
+};
+vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *out);
+
+}  // namespace vslam

@@ -1,0 +1,185 @@
+// Context lifecycle, status strings, camera.xml reader.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace vslam {
+
+vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->ws) {
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        VSLAM_HIP_TRY(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2) + (1u << 20);
+    hipError_t e = hipMalloc(&ctx->ws, want);
+    if (e != hipSuccess) return fail(ctx, VSLAM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->ws_bytes = want;
+    return VSLAM_OK;
+}
+
+vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *k)
+{
+    const int RATIONAL = 0x4000, THIN = 0x8000;
+    if (!cam) return fail(ctx, VSLAM_ERR_ARG, "camera is null");
+    if (cam->flag & ~(RATIONAL | THIN))
+        return fail(ctx, VSLAM_ERR_UNSUPPORTED, "calibration flag %d: only RATIONAL|THIN_PRISM are supported", cam->flag);
+    bool rational = (cam->flag & RATIONAL) == RATIONAL, thin = (cam->flag & THIN) == THIN;
+    k->fx = cam->fx; k->fy = cam->fy; k->cx = cam->cx; k->cy = cam->cy;
+    k->k1 = cam->d[0]; k->k2 = cam->d[1]; k->p1 = cam->d[2]; k->p2 = cam->d[3]; k->k3 = cam->d[4];
+    if (rational) {
+        const double *s = thin ? cam->d + 8 : cam->d + 5;
+        k->s1 = s[0]; k->s2 = s[1]; k->s3 = s[2]; k->s4 = s[3];
+    } else {
+        k->s1 = k->s2 = k->s3 = k->s4 = 0.0;
+    }
+    if (thin) { k->k4 = cam->d[5]; k->k5 = cam->d[6]; k->k6 = cam->d[7]; }
+    else      { k->k4 = k->k5 = k->k6 = 0.0; }
+    const double pi = 3.14159265358979323846264338327950288;
+    k->cos_half_fov = std::cos(cam->fov_deg * ((pi / 180.0) / 2.));
+    k->wmax = double(cam->width - 1);
+    k->hmax = double(cam->height - 1);
+    return VSLAM_OK;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+extern "C" {
+
+int vslam_has_device_code(void) { return 1; }
+
+const char *vslam_status_string(vslam_status s)
+{
+    switch (s) {
+    case VSLAM_OK: return "ok";
+    case VSLAM_ERR_ARG: return "invalid argument";
+    case VSLAM_ERR_SHAPE: return "shape mismatch";
+    case VSLAM_ERR_DEVICE: return "HIP runtime error";
+    case VSLAM_ERR_ALLOC: return "allocation failed";
+    case VSLAM_ERR_IO: return "I/O error";
+    case VSLAM_ERR_CAPACITY: return "capacity exceeded";
+    case VSLAM_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+    }
+}
+
+const char *vslam_last_error(const vslam_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **out)
+{
+    if (!out) return VSLAM_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VSLAM_ERR_DEVICE;
+    if (device < 0 || device >= count) return VSLAM_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return VSLAM_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VSLAM_ERR_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "libvslam_hip: device %d is %s; this library carries gfx950 code only\n", device,
+                     prop.gcnArchName);
+        return VSLAM_ERR_UNSUPPORTED;
+    }
+    vslam_ctx *c = new vslam_ctx();
+    c->device = device;
+    if (borrow) {
+        c->stream = static_cast<hipStream_t>(stream);
+        c->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VSLAM_ERR_DEVICE; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_ctx_create(int device, vslam_ctx **out) { return ctx_make(device, nullptr, false, out); }
+vslam_status vslam_ctx_create_on_stream(int device, void *hip_stream, vslam_ctx **out)
+{
+    return ctx_make(device, hip_stream, true, out);
+}
+
+vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VSLAM_OK;
+}
+
+vslam_status vslam_ctx_synchronize(vslam_ctx *ctx)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VSLAM_OK;
+}
+
+// Reads the numbers of <tag> ... <data> n n n </data> ... </tag>.
+static bool xml_block(const std::string &txt, const char *tag, std::string *body)
+{
+    std::string open = std::string("<") + tag;
+    size_t a = txt.find(open);
+    if (a == std::string::npos) return false;
+    a = txt.find('>', a);
+    if (a == std::string::npos) return false;
+    size_t b = txt.find(std::string("</") + tag + ">", a);
+    if (b == std::string::npos) return false;
+    *body = txt.substr(a + 1, b - a - 1);
+    return true;
+}
+static bool xml_numbers(const std::string &body, std::vector<double> *v)
+{
+    std::istringstream is(body);
+    std::string tok;
+    v->clear();
+    while (is >> tok) {
+        char *end = nullptr;
+        double d = std::strtod(tok.c_str(), &end);
+        if (end == tok.c_str() || *end != '\0') return false;
+        v->push_back(d);
+    }
+    return true;
+}
+
+vslam_status vslam_camera_from_xml(const char *path, vslam_camera *cam)
+{
+    if (!path || !cam) return VSLAM_ERR_ARG;
+    std::ifstream f(path);
+    if (!f) return VSLAM_ERR_IO;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string txt = ss.str(), K, D, body, data;
+    std::vector<double> v;
+    std::memset(cam, 0, sizeof *cam);
+    cam->fov_deg = 120.0;
+    if (!xml_block(txt, "camera_matrix", &K) || !xml_block(K, "data", &data) || !xml_numbers(data, &v) || v.size() != 9)
+        return VSLAM_ERR_IO;
+    cam->fx = v[0]; cam->cx = v[2]; cam->fy = v[4]; cam->cy = v[5];
+    if (!xml_block(txt, "distortion_coefficients", &D) || !xml_block(D, "data", &data) || !xml_numbers(data, &v) ||
+        v.empty() || v.size() > 12)
+        return VSLAM_ERR_IO;
+    for (size_t i = 0; i < v.size(); ++i) cam->d[i] = v[i];
+    if (!xml_block(txt, "flag", &body) || !xml_numbers(body, &v) || v.size() != 1) return VSLAM_ERR_IO;
+    cam->flag = int32_t(v[0]);
+    if (!xml_block(txt, "imageSize", &body) || !xml_numbers(body, &v) || v.size() != 2) return VSLAM_ERR_IO;
+    cam->width = int32_t(v[0]);
+    cam->height = int32_t(v[1]);
+    return VSLAM_OK;
+}
+
+}  // extern "C"
