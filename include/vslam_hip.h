@@ -68,7 +68,9 @@ typedef struct {
 } vslam_corner_params;
 
 enum { VSLAM_LAYOUT_COMPAT = 0, VSLAM_LAYOUT_STRICT = 1 };
-enum { VSLAM_DETECTOR_HARRIS = 0, VSLAM_DETECTOR_SHI_TOMASI = 1 };
+/* BOTH runs the two detectors off one structure tensor: out holds 2*cap records
+ * (Harris first, then Shi-Tomasi) and count two entries per frame. */
+enum { VSLAM_DETECTOR_HARRIS = 0, VSLAM_DETECTOR_SHI_TOMASI = 1, VSLAM_DETECTOR_BOTH = 2 };
 
 /* ---- context ---- */
 /* Creates a context on `device` with its own non-blocking stream. */
@@ -178,7 +180,9 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
  * Harris (or Shi-Tomasi) response, sorted by response.  gray is w x h u8 with
  * row stride `stride` bytes.  out[cap] receives min(count, cap, max_features)
  * records sorted by score descending (ties: y, then x ascending); *count is
- * the number written. */
+ * the number written.  At most 65536 candidates may survive NMS per detector
+ * (VSLAM_ERR_CAPACITY otherwise; the batch form reports count = -1 for such a
+ * frame) and max_features <= 16384. */
 vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
                                  const vslam_corner_params *params, int detector,
                                  vslam_feature *out, int cap, int32_t *count);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* Same layout as vslam_camera in include/vslam_hip.h (160 bytes). */
+/* Same layout as vslam_camera in include/vslam_hip.h (152 bytes). */
 typedef struct {
     double fx, fy, cx, cy;
     double d[12];      /* OpenCV order: k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4 */

@@ -1,0 +1,407 @@
+// Corner front end: Harris / Shi-Tomasi response, 3x3 non-maximum suppression,
+// thresholding and score-sorted keypoint output, as LDS-tiled stencil kernels.
+//
+// Stands in for the feature stage of detectAndDrawORB (reference
+// src/imagefeatures.cpp:71-96, cv::ORB with HARRIS_SCORE) as consumed by
+// src/SLAM.cpp:449-472 (sort by response, threshold, pick).  The arithmetic
+// contract (the reference delegates it to OpenCV):
+//   Ix, Iy   3x3 Sobel on the u8 image, exact int32
+//   a, b, c  block_size^2 window sums of Ix^2, Iy^2, Ix*Iy, exact int32
+//   s = 1/(4*block_size*255), s2 = s*s, s4 = s2*s2                (float32)
+//   Harris   ((fa*fb - fc*fc) - k*((fa+fb)*(fa+fb))) * s4         (float32, one
+//            rounding per operation, no fused multiply-add)
+//   Shi-T.   ((fa+fb)*0.5f - sqrtf(d*d + fc*fc)) * s2, d=(fa-fb)*0.5f
+//   valid    pixels >= 1+block_size/2 from every edge, 0 elsewhere
+//   NMS      strictly greater than the 4 raster-preceding neighbours,
+//            greater-or-equal than the 4 following ones
+//   output   response > threshold, inside the border; sorted by score
+//            descending, then y, then x ascending; first max_features.
+//
+// Kernel 1 (corner_tile_kernel): one workgroup per 64x32 output tile.  The u8
+// tile plus a (block/2+2)-pixel halo is read once from HBM with coalesced row
+// loads into LDS; gradients -> products -> separable window sums -> response
+// -> NMS all stay in LDS.  Survivors are appended (wave-aggregated atomics) to
+// a per-frame candidate list as 64-bit sort keys that encode score, y and x.
+// Kernel 2 (sort_chunk_kernel): bitonic sort of up to 16384 keys in LDS by one
+// 1024-thread workgroup per chunk; kernel 3 merges sorted chunks pairwise
+// keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
+// unpacks the leading keys into Feature records.
+#include "common.hpp"
+
+namespace vslam {
+
+constexpr int TW = 64, TH = 32;            // output tile
+constexpr int MAXHB = 7;                   // block_size <= 15
+constexpr int SORT_S = 16384;              // keys per LDS sort
+constexpr int CAND_CHUNKS = 4;             // candidate capacity = 4 * SORT_S per frame and detector
+constexpr int CAND_CAP = CAND_CHUNKS * SORT_S;
+
+__device__ __forceinline__ uint64_t make_key(float score, int x, int y)
+{
+    uint32_t u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // order-preserving float -> uint
+    uint32_t lo = ~(((uint32_t)y << 16) | (uint32_t)x);      // smaller (y,x) sorts first
+    return ((uint64_t)u << 32) | lo;
+}
+__device__ __forceinline__ void unpack_key(uint64_t key, vslam_feature *f)
+{
+    uint32_t u = (uint32_t)(key >> 32), lo = ~(uint32_t)key;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    f->score = __uint_as_float(u);
+    f->x = (int32_t)(lo & 0xffffu);
+    f->y = (int32_t)(lo >> 16);
+}
+
+struct CornerArgs {
+    const uint8_t *gray; size_t stride_frame;
+    int w, h, stride;
+    int bs, border;
+    float k, thr_h, thr_s;
+    float s2, s4;
+    uint64_t *cand;        // [frame][det][CAND_CAP]
+    int32_t *cand_count;   // [frame][det]
+    float *map_h, *map_s;  // dense maps (MAPS mode), single frame
+};
+
+// DET: bit0 Harris, bit1 Shi-Tomasi.  MAPS: write dense response maps instead of keypoints.
+template <int DET, bool MAPS>
+__global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int hb = a.bs >> 1, R = hb + 1;          // response needs image +-R
+    const int halo = R + 1;                        // +1 for the NMS ring
+    const int IW = TW + 2 * halo, IH = TH + 2 * halo;      // image tile
+    const int GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1);  // gradient-product tile (response ring +-hb)
+    const int RW = TW + 2, RH = TH + 2;            // response tile
+    // LDS carve-up
+    int32_t *pa = reinterpret_cast<int32_t *>(smem);               // GW*GH   Ix^2   (later: response maps)
+    int32_t *pb = pa + GW * GH;                                    //         Iy^2
+    int32_t *pc = pb + GW * GH;                                    //         IxIy
+    int32_t *ha = pc + GW * GH;                                    // RW*GH   horizontal sums
+    int32_t *hbb = ha + RW * GH;
+    int32_t *hc = hbb + RW * GH;
+    uint8_t *img = reinterpret_cast<uint8_t *>(hc + RW * GH);      // IW*IH
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const uint8_t *gray = a.gray + (size_t)blockIdx.z * a.stride_frame;
+    const int w = a.w, h = a.h;
+
+    // ---- 1. image tile (clamped reads; clamped pixels only feed invalid outputs) ----
+    for (int i = tid; i < IW * IH; i += 256) {
+        int ly = i / IW, lx = i - ly * IW;
+        int gx = min(max(x0 - halo + lx, 0), w - 1), gy = min(max(y0 - halo + ly, 0), h - 1);
+        img[i] = gray[(size_t)gy * a.stride + gx];
+    }
+    __syncthreads();
+    // ---- 2. Sobel gradients and their products on the GW x GH tile (image offset +1) ----
+    for (int i = tid; i < GW * GH; i += 256) {
+        int ly = i / GW, lx = i - ly * GW;
+        const uint8_t *r0 = img + ly * IW + lx, *r1 = r0 + IW, *r2 = r1 + IW;
+        int ix = ((int)r0[2] - (int)r0[0]) + 2 * ((int)r1[2] - (int)r1[0]) + ((int)r2[2] - (int)r2[0]);
+        int iy = ((int)r2[0] - (int)r0[0]) + 2 * ((int)r2[1] - (int)r0[1]) + ((int)r2[2] - (int)r0[2]);
+        pa[i] = ix * ix; pb[i] = iy * iy; pc[i] = ix * iy;
+    }
+    __syncthreads();
+    // ---- 3. horizontal window sums: RW x GH ----
+    for (int i = tid; i < RW * GH; i += 256) {
+        int ly = i / RW, lx = i - ly * RW;
+        const int32_t *qa = pa + ly * GW + lx, *qb = pb + ly * GW + lx, *qc = pc + ly * GW + lx;
+        int sa = 0, sb = 0, sc = 0;
+        for (int t = 0; t < a.bs; ++t) { sa += qa[t]; sb += qb[t]; sc += qc[t]; }
+        ha[i] = sa; hbb[i] = sb; hc[i] = sc;
+    }
+    __syncthreads();
+    // ---- 4. vertical sums + response: RW x RH, stored over the product buffers ----
+    float *resp_h = reinterpret_cast<float *>(pa), *resp_s = reinterpret_cast<float *>(pb);
+    for (int i = tid; i < RW * RH; i += 256) {
+        int ly = i / RW, lx = i - ly * RW;
+        int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        int sa = 0, sb = 0, sc = 0;
+        for (int t = 0; t < a.bs; ++t) { sa += ha[(ly + t) * RW + lx]; sb += hbb[(ly + t) * RW + lx]; sc += hc[(ly + t) * RW + lx]; }
+        bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
+        float fa = (float)sa, fb = (float)sb, fc = (float)sc;
+        float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
+        if (DET & 1) {
+            float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
+            float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
+            resp_h[i] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
+        }
+        if (DET & 2) {
+            float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
+            // correctly rounded float sqrt via fp64 (53 >= 2*24+2 bits: the double rounding is exact)
+            float root = (float)sqrt((double)__fadd_rn(__fmul_rn(d, d), t2));
+            resp_s[i] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- 5. maps, or NMS + threshold + append ----
+    for (int i = tid; i < TW * TH; i += 256) {
+        int ly = i / TW, lx = i - ly * TW;
+        int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= w || gy >= h) continue;
+        const int c = (ly + 1) * RW + (lx + 1);
+        if (MAPS) {
+            if ((DET & 1) && a.map_h) a.map_h[(size_t)gy * w + gx] = resp_h[c];
+            if ((DET & 2) && a.map_s) a.map_s[(size_t)gy * w + gx] = resp_s[c];
+            continue;
+        }
+        if (gx < a.border || gy < a.border || gx >= w - a.border || gy >= h - a.border) continue;
+#pragma unroll
+        for (int det = 0; det < 2; ++det) {
+            if (!(DET & (1 << det))) continue;
+            const float *rp = det == 0 ? resp_h : resp_s;
+            const float thr = det == 0 ? a.thr_h : a.thr_s;
+            float r = rp[c];
+            if (!(r > thr)) continue;
+            bool ok = r > rp[c - RW - 1] && r > rp[c - RW] && r > rp[c - RW + 1] && r > rp[c - 1] &&
+                      r >= rp[c + 1] && r >= rp[c + RW - 1] && r >= rp[c + RW] && r >= rp[c + RW + 1];
+            if (!ok) continue;
+            int32_t *cnt = a.cand_count + ((size_t)blockIdx.z * 2 + det);
+            int slot = atomicAdd(cnt, 1);
+            if (slot < CAND_CAP) a.cand[((size_t)blockIdx.z * 2 + det) * CAND_CAP + slot] = make_key(r, gx, gy);
+        }
+    }
+}
+
+// Bitonic sort (descending) of one chunk of candidate keys in LDS.
+// grid = (CAND_CHUNKS, frames, 2 detectors); chunks beyond the candidate count exit.
+__global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    const int det = blockIdx.z;
+    if (!(det_mask & (1 << det))) return;
+    const size_t list = (size_t)blockIdx.y * 2 + det;
+    const int total = min(cand_count[list], CAND_CAP);
+    const int base = blockIdx.x * SORT_S;
+    if (base >= total) return;
+    const int nloc = min(SORT_S, total - base);
+    int S = 1024;
+    while (S < nloc) S <<= 1;
+    uint64_t *src = cand + list * CAND_CAP + base;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S; i += 1024) keys[i] = (i < nloc) ? src[i] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= S; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (S >> 1); t += 1024) {
+                int i = 2 * t - (t & (j - 1));          // lower index of the pair
+                int p = i + j;
+                bool desc = (i & k) == 0;
+                uint64_t a = keys[i], b = keys[p];
+                if ((a < b) == desc) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // write back the sorted chunk, padded to SORT_S with zeros so merges can read blindly
+    for (int i = tid; i < SORT_S; i += 1024) src[i] = (i < S) ? keys[i] : 0ull;
+}
+
+// Merge sorted chunks c and c+step (both descending, zero padded) keeping the top SORT_S in chunk c.
+__global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, const int32_t *cand_count, int step, int det_mask)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    const int det = blockIdx.z;
+    if (!(det_mask & (1 << det))) return;
+    const size_t list = (size_t)blockIdx.y * 2 + det;
+    const int total = min(cand_count[list], CAND_CAP);
+    const int ca = blockIdx.x * 2 * step, cb = ca + step;
+    if (cb * SORT_S >= total) return;                   // partner chunk is empty
+    uint64_t *A = cand + list * CAND_CAP + (size_t)ca * SORT_S;
+    const uint64_t *B = cand + list * CAND_CAP + (size_t)cb * SORT_S;
+    const int tid = threadIdx.x;
+    // max(A[i], B[S-1-i]) is the top-S set as a bitonic sequence
+    for (int i = tid; i < SORT_S; i += 1024) {
+        uint64_t x = A[i], y = B[SORT_S - 1 - i];
+        keys[i] = x > y ? x : y;
+    }
+    __syncthreads();
+    for (int j = SORT_S >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (SORT_S >> 1); t += 1024) {
+            int i = 2 * t - (t & (j - 1)), p = i + j;
+            uint64_t a = keys[i], b = keys[p];
+            if (a < b) { keys[i] = b; keys[p] = a; }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < SORT_S; i += 1024) A[i] = keys[i];
+}
+
+// Unpacks the leading keys of each list into Feature records.
+__global__ void emit_features_kernel(const uint64_t *cand, const int32_t *cand_count, int det_first, int ndet,
+                                     int cap, int max_features, vslam_feature *out, int32_t *count)
+{
+    const int f = blockIdx.y, d = blockIdx.z;                  // d indexes the requested detectors
+    const int det = det_first + d;
+    const size_t list = (size_t)f * 2 + det;
+    const int raw = cand_count[list];
+    const int total = min(raw, CAND_CAP);
+    int nout = min(min(total, cap), min(max_features, SORT_S));
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) count[(size_t)f * ndet + d] = raw > CAND_CAP ? -1 : nout;   // -1: candidate list overflowed
+    if (i >= nout) return;
+    vslam_feature ft;
+    unpack_key(cand[list * CAND_CAP + i], &ft);
+    out[((size_t)f * ndet + d) * cap + i] = ft;
+}
+
+static size_t tile_lds_bytes(int bs)
+{
+    const int hb = bs / 2, halo = hb + 2;
+    const int IW = TW + 2 * halo, IH = TH + 2 * halo, GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1), RW = TW + 2;
+    size_t b = (size_t)GW * GH * 4 * 3 + (size_t)RW * GH * 4 * 3 + (size_t)IW * IH;
+    return (b + 15) & ~size_t(15);
+}
+
+static vslam_status check_params(vslam_ctx *ctx, const vslam_corner_params *p, int w, int h, int stride, int detector)
+{
+    if (!p) return fail(ctx, VSLAM_ERR_ARG, "corner: null params");
+    if (p->block_size < 3 || p->block_size > 2 * MAXHB + 1 || !(p->block_size & 1))
+        return fail(ctx, VSLAM_ERR_ARG, "corner: block_size %d must be odd in [3,15]", p->block_size);
+    if (p->border < p->block_size / 2 + 2) return fail(ctx, VSLAM_ERR_ARG, "corner: border %d < block_size/2+2", p->border);
+    if (w < 2 * p->border + 1 || h < 2 * p->border + 1 || stride < w) return fail(ctx, VSLAM_ERR_SHAPE, "corner: image %dx%d (stride %d) too small", w, h, stride);
+    if (w > 65535 || h > 65535) return fail(ctx, VSLAM_ERR_CAPACITY, "corner: image side exceeds 65535");
+    if (detector < 0 || detector > 2) return fail(ctx, VSLAM_ERR_ARG, "corner: bad detector %d", detector);
+    if (p->max_features < 1 || p->max_features > SORT_S) return fail(ctx, VSLAM_ERR_CAPACITY, "corner: max_features %d outside [1,%d]", p->max_features, SORT_S);
+    return VSLAM_OK;
+}
+
+static CornerArgs make_args(const uint8_t *gray, int w, int h, int stride, size_t stride_frame, const vslam_corner_params *p)
+{
+    CornerArgs a;
+    a.gray = gray; a.stride_frame = stride_frame; a.w = w; a.h = h; a.stride = stride;
+    a.bs = p->block_size; a.border = p->border; a.k = p->harris_k; a.thr_h = p->harris_thresh; a.thr_s = p->shi_thresh;
+    volatile float s = 1.0f / (4.0f * (float)p->block_size * 255.0f);
+    volatile float s2 = s * s;
+    volatile float s4 = s2 * s2;
+    a.s2 = s2; a.s4 = s4;
+    a.cand = nullptr; a.cand_count = nullptr; a.map_h = nullptr; a.map_s = nullptr;
+    return a;
+}
+
+// Workspace per frame: 2 candidate lists + 2 counters.
+static size_t detect_ws_bytes(int frames) { return Arena::pad((size_t)frames * 2 * CAND_CAP * 8) + Arena::pad((size_t)frames * 2 * 4); }
+
+static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int detector, const vslam_corner_params *p,
+                                  vslam_feature *out, int cap, int32_t *count, void *ws)
+{
+    Arena ar(ws);
+    a.cand = ar.take<uint64_t>((size_t)frames * 2 * CAND_CAP);
+    a.cand_count = ar.take<int32_t>((size_t)frames * 2);
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(a.cand_count, 0, (size_t)frames * 2 * 4, s));
+    dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH, frames);
+    size_t lds = tile_lds_bytes(a.bs);
+    const int det_mask = detector == 2 ? 3 : (1 << detector);
+    if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false>), grid, dim3(256), lds, s, a);
+    else if (det_mask == 2) hipLaunchKernelGGL((corner_tile_kernel<2, false>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((corner_tile_kernel<3, false>), grid, dim3(256), lds, s, a);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, det_mask);
+    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
+        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s,
+                           a.cand, a.cand_count, step, det_mask);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    const int ndet = detector == 2 ? 2 : 1, det_first = detector == 2 ? 0 : detector;
+    const int lim = cap < p->max_features ? cap : p->max_features;
+    hipLaunchKernelGGL(emit_features_kernel, dim3((lim + 255) / 256, frames, ndet), dim3(256), 0, s, a.cand, a.cand_count,
+                       det_first, ndet, cap, p->max_features, out, count);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+static vslam_status ensure_lds_attr(vslam_ctx *ctx)
+{
+    static bool done = false;
+    if (done) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
+    const int big = (int)tile_lds_bytes(2 * MAXHB + 1);
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    done = true;
+    return VSLAM_OK;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+extern "C" vslam_status vslam_corner_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                                      size_t stride_frame, int frames, const vslam_corner_params *params,
+                                                      int detector, vslam_feature *out, int cap, int32_t *count)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "corner_detect: null pointer or cap < 1");
+    if (frames < 1 || frames > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "corner_detect: frames=%d out of range", frames);
+    VSLAM_TRY(check_params(ctx, params, w, h, stride, detector));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    VSLAM_TRY(ws_reserve(ctx, detect_ws_bytes(frames)));
+    CornerArgs a = make_args(gray, w, h, stride, stride_frame, params);
+    return launch_detect(ctx, a, frames, detector, params, out, cap, count, ctx->ws);
+}
+
+extern "C" vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                            const vslam_corner_params *params, int detector,
+                                            vslam_feature *out, int cap, int32_t *count)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "corner_detect: null pointer or cap < 1");
+    VSLAM_TRY(check_params(ctx, params, w, h, stride, detector));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    const int ndet = detector == 2 ? 2 : 1;
+    const size_t img_bytes = (size_t)stride * h, out_bytes = (size_t)ndet * cap * sizeof(vslam_feature);
+    VSLAM_TRY(ws_reserve(ctx, detect_ws_bytes(1) + Arena::pad(img_bytes) + Arena::pad(out_bytes) + Arena::pad(8)));
+    Arena ar(ctx->ws);
+    void *dws = ar.take<char>(detect_ws_bytes(1));
+    uint8_t *dimg = ar.take<uint8_t>(img_bytes);
+    vslam_feature *dout = ar.take<vslam_feature>((size_t)ndet * cap);
+    int32_t *dcount = ar.take<int32_t>(2);
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dimg, gray, img_bytes, hipMemcpyHostToDevice, s));
+    CornerArgs a = make_args(dimg, w, h, stride, 0, params);
+    VSLAM_TRY(launch_detect(ctx, a, 1, detector, params, dout, cap, dcount, dws));
+    int32_t hc[2] = {0, 0};
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(hc, dcount, ndet * 4, hipMemcpyDeviceToHost, s));
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (int d = 0; d < ndet; ++d) {
+        if (hc[d] < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "corner_detect: more than %d candidates survive NMS; raise the threshold", CAND_CAP);
+        count[d] = hc[d];
+        if (hc[d] > 0)
+            VSLAM_HIP_TRY(ctx, hipMemcpy(out + (size_t)d * cap, dout + (size_t)d * cap, (size_t)hc[d] * sizeof(vslam_feature), hipMemcpyDeviceToHost));
+    }
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                              const vslam_corner_params *params, float *harris, float *shi)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray) return fail(ctx, VSLAM_ERR_ARG, "corner_response: null image");
+    VSLAM_TRY(check_params(ctx, params, w, h, stride, 2));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    const size_t img_bytes = (size_t)stride * h, map_bytes = (size_t)w * h * 4;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(img_bytes) + 2 * Arena::pad(map_bytes)));
+    Arena ar(ctx->ws);
+    uint8_t *dimg = ar.take<uint8_t>(img_bytes);
+    float *dh = ar.take<float>((size_t)w * h), *ds = ar.take<float>((size_t)w * h);
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dimg, gray, img_bytes, hipMemcpyHostToDevice, s));
+    CornerArgs a = make_args(dimg, w, h, stride, 0, params);
+    a.map_h = dh; a.map_s = ds;
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, 1);
+    hipLaunchKernelGGL((corner_tile_kernel<3, true>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    if (harris) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(harris, dh, map_bytes, hipMemcpyDeviceToHost, s));
+    if (shi) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(shi, ds, map_bytes, hipMemcpyDeviceToHost, s));
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    return VSLAM_OK;
+}
