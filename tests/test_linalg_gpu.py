@@ -1,0 +1,126 @@
+"""GPU checks of the fp64 MFMA GEMM and the blocked Householder QR.
+QR sign convention is pinned by the reference's affineTransform known answers
+(test/src/affineTransform.cpp) and equals LAPACK's, so numpy.linalg.qr(mode='r')
+is the independent check at sizes the oracle's unblocked QR would take long."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(ctx, A, B, transA=False, transB=False, amode=0, b_upper=False, alpha=1.0, beta=0.0, Cin=None, ksplit=1):
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    A = np.asfortranarray(A, dtype=np.float64)
+    B = np.asfortranarray(B, dtype=np.float64)
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    out = np.zeros((M, N * max(ksplit, 1)), order="F") if Cin is None else np.array(Cin, dtype=np.float64, order="F")
+    fn = L.vslam_debug_gemm
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    st = fn(ctx.ptr, M, N, K, int(transA), int(transB), amode, int(b_upper), alpha, A.ctypes.data, A.shape[0],
+            A.shape[0], A.shape[1], B.ctypes.data, B.shape[0], B.shape[0], B.shape[1], beta, out.ctypes.data, M, ksplit)
+    assert st == 0, L.vslam_last_error(ctx.ptr)
+    if ksplit > 1:
+        return out.reshape(M, N, ksplit, order="F").sum(axis=2)
+    return out
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(16, 16, 4), (64, 64, 16), (70, 45, 33), (32, 200, 300), (129, 65, 7), (1, 1, 1)])
+def test_gemm_layouts(ctx, ta, tb, M, N, K):
+    """Asymmetric integer data: any row/column swap in the MFMA fragment maps shows up exactly."""
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.integers(-9, 10, (K, M) if ta else (M, K)).astype(np.float64)
+    B = rng.integers(-9, 10, (N, K) if tb else (K, N)).astype(np.float64)
+    want = (A.T if ta else A) @ (B.T if tb else B)
+    got = _gemm(ctx, A, B, ta, tb)
+    assert np.array_equal(got, want)
+
+
+def test_gemm_alpha_beta_masks_split(ctx):
+    rng = np.random.default_rng(3)
+    M, N, K = 150, 90, 40
+    V = rng.standard_normal((M, K))
+    Vm = np.tril(V, -1) + np.eye(M, K)                        # unit-lower view of V
+    B = rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    got = _gemm(ctx, V, B, amode=1, alpha=-1.0, beta=1.0, Cin=C0)
+    assert rel_err(got, C0 - Vm @ B) <= 1e-13
+    W = _gemm(ctx, V, rng.standard_normal((M, N)) * 0 + C0, transA=True, amode=1, ksplit=5)
+    assert rel_err(W, Vm.T @ C0) <= 1e-13
+    U = np.triu(rng.standard_normal((K, K)))
+    Ufull = U + np.tril(rng.standard_normal((K, K)), -1)       # garbage below the diagonal must be ignored
+    got = _gemm(ctx, Ufull, B, amode=2)
+    assert rel_err(got, U @ B) <= 1e-13
+    got = _gemm(ctx, V, Ufull, b_upper=True)
+    assert rel_err(got, V @ U) <= 1e-13
+
+
+@pytest.mark.parametrize("m,k", [(2, 2), (5, 3), (33, 32), (64, 64), (97, 31), (30, 50), (462, 462), (762, 300), (1500, 700)])
+def test_qr_vs_lapack(ctx, m, k):
+    from visualslam_amd import api
+    rng = np.random.default_rng(m + k)
+    A = rng.standard_normal((m, k))
+    R = api.qr_upper(ctx, A)
+    R0 = np.linalg.qr(A, mode="r")
+    r = min(m, k)
+    assert rel_err(R[:r], R0) <= 1e-11
+    assert not np.tril(R, -1).any()
+
+
+def test_qr_vs_oracle_and_edge_cases(ctx):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((90, 70))
+    assert rel_err(api.qr_upper(ctx, A), orc.qr_upper(A)) <= 1e-11
+    # already upper triangular with zero tails: columns keep their sign (tau = 0)
+    U = np.triu(rng.standard_normal((40, 40)))
+    assert rel_err(api.qr_upper(ctx, U), orc.qr_upper(U)) <= 1e-12
+    # rank-deficient / zero matrix
+    Z = np.zeros((20, 10))
+    assert not api.qr_upper(ctx, Z).any()
+    # sqrt-covariance-like input: R^T R = A^T A
+    S = np.triu(rng.standard_normal((200, 200))) * 0.01 + np.diag(rng.uniform(0.001, 0.5, 200))
+    G = rng.standard_normal((260, 200)) @ S
+    R = api.qr_upper(ctx, G)
+    assert rel_err(R[:200].T @ R[:200], G.T @ G) <= 1e-11
+
+
+def test_affine_kats_on_gpu(ctx):
+    """test/src/affineTransform.cpp:59-64,125-130 through the device QR."""
+    from visualslam_amd import api
+    for mux, Sxx, Syy in (([1., 3.], [10., 1.], [[-3.00171694492, -3.12886418774], [0, -1.05839921328]]),
+                          ([1., 1.], [1.5, 1.8], [[-1.17166745172, 0.298734812658], [0, -1.63271476741]])):
+        x = np.array(mux)
+        n2 = x @ x
+        J = np.array([[x[1] / n2, -x[0] / n2], [x[0] / np.sqrt(n2), x[1] / np.sqrt(n2)]])
+        SR = np.diag([np.pi / 180, 0.1])
+        A = np.vstack([np.diag(Sxx) @ J.T, SR])
+        R = api.qr_upper(ctx, A)
+        assert np.allclose(R[:2], np.array(Syy), rtol=1e-10, atol=1e-12)
+
+
+def test_qr_batched_dev(ctx):
+    import torch
+    from visualslam_amd import api
+    rng = np.random.default_rng(9)
+    B, m, k = 5, 130, 100
+    A = rng.standard_normal((B, k, m))                        # each instance column-major (m x k)
+    t = torch.tensor(A, device="cuda:0")
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    api.qr_upper_batch_dev(tctx, t, m, k, m, B, m * k)
+    torch.cuda.synchronize()
+    out = t.cpu().numpy()
+    for b in range(B):
+        R0 = np.linalg.qr(A[b].T, mode="r")
+        assert rel_err(out[b].T[:k], R0) <= 1e-11
+    tctx.close()

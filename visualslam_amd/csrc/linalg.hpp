@@ -1,0 +1,50 @@
+// Device-side dense fp64 building blocks (column-major, device pointers, all
+// queued on ctx->stream): MFMA GEMM, blocked Householder QR, triangular
+// inverse / solves.  Declarations only; kernels live in gemm.hip / qr.hip /
+// tri.hip.
+#pragma once
+
+#include "common.hpp"
+
+namespace vslam {
+
+// How the A operand of a GEMM is read from memory.
+enum AMode {
+    A_PLAIN = 0,
+    A_UNIT_LOWER = 1,   // Householder vectors stored below the diagonal of a panel:
+                        // element (r,c) reads 0 for r<c, 1 for r==c, memory for r>c
+    A_UPPER = 2,        // upper-triangular matrix: element (r,c) reads 0 for r>c
+};
+
+struct GemmDesc {
+    int M, N, K;
+    bool transA, transB;     // op(A) is M x K, op(B) is K x N
+    AMode amode = A_PLAIN;   // applies to the stored A matrix coordinates
+    bool b_upper = false;    // stored B is upper triangular (reads 0 below the diagonal)
+    double alpha = 1.0, beta = 0.0;
+    const double *A; int lda; size_t strideA = 0;
+    const double *B; int ldb; size_t strideB = 0;
+    double *C; int ldc; size_t strideC = 0;
+    int batch = 1;
+    int ksplit = 1;          // >1: split K; slab s of batch b is written (beta ignored) at
+    size_t strideSplit = 0;  //     C + b*strideC + s*strideSplit
+};
+
+// C = alpha * op(A) * op(B) + beta * C on v_mfma_f64_16x16x4_f64.
+vslam_status gemm_f64(vslam_ctx *ctx, const GemmDesc &d);
+
+// In-place Householder QR of `batch` matrices (rows x cols, leading dimension
+// lda, element stride strideA); on return the upper triangle holds R (LAPACK /
+// Eigen sign convention) and the strict lower triangle is zero.  `ws` must
+// hold qr_ws_bytes(rows, cols, batch) bytes.
+size_t qr_ws_bytes(int rows, int cols, int batch);
+vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws);
+
+// W = inverse of the upper-triangular S (n x n); strict lower part of W zeroed.
+size_t trtri_ws_bytes(int n);
+vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws);
+
+// Solves S^T z = b (trans = true) or S z = b (trans = false) for one vector, S upper triangular.
+vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z);
+
+}  // namespace vslam
