@@ -1,0 +1,138 @@
+"""GPU parity of the square-root Gaussian algebra (logGaussian, affineTransform,
+conditioning, joint cost) and of the full iterated-EKF measurement update
+against the CPU oracle and the reference's known answers.  fp64, 1e-9 relative
+unless a test states otherwise."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def test_log_gaussian_reference_kats(ctx):
+    """test/src/logGaussian.cpp:10-155"""
+    from visualslam_amd import api
+    v, g, H = api.log_gaussian(ctx, [1., 2, 3], [2., 4, 6], np.diag([1., 2, 3]))
+    assert v == pytest.approx(-6.04857506884207, rel=1e-13)
+    assert np.allclose(g, [1.0, 0.5, 1 / 3.0], rtol=1e-13)
+    assert np.allclose(H, np.diag([-1.0, -0.25, -1 / 9.0]), rtol=1e-13, atol=1e-10)
+    mu = np.array([np.sqrt(350 * np.log(10) / np.pi)])
+    v, _, _ = api.log_gaussian(ctx, np.zeros(1), mu, np.array([[1.0 / np.sqrt(2 * np.pi)]]), False, False)
+    assert v == pytest.approx(-805.904782547916, rel=1e-13)
+    for a in (1e-4, 1e4):                               # determinant under/overflow
+        n = 100
+        v, _, _ = api.log_gaussian(ctx, np.zeros(n), np.zeros(n), a * np.eye(n), False, False)
+        assert v == pytest.approx(-n * np.log(a) - n / 2.0 * np.log(2 * np.pi), rel=1e-13)
+
+
+@pytest.mark.parametrize("n", [1, 5, 33, 162, 462, 700])
+def test_log_gaussian_vs_oracle(ctx, n):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(n)
+    S = np.triu(rng.standard_normal((n, n))) * 0.05 + np.diag(rng.uniform(0.2, 1.5, n) * rng.choice([-1, 1], n))
+    x, mu = rng.standard_normal(n), rng.standard_normal(n)
+    v, g, H = api.log_gaussian(ctx, x, mu, S)
+    v0, g0, H0 = orc.log_gaussian(x, mu, S)
+    assert abs(v - v0) <= TOL * abs(v0) and rel_err(g, g0) <= TOL and rel_err(H, H0) <= TOL
+    v1, g1, H1 = api.log_gaussian(ctx, x, mu, S, want_g=True, want_H=False)
+    assert H1 is None and v1 == v and np.array_equal(g1, g)
+
+
+@pytest.mark.parametrize("n,m", [(2, 2), (12, 5), (162, 100), (462, 300)])
+def test_affine_sqrt_vs_oracle(ctx, n, m):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(n * 7 + m)
+    S = np.triu(rng.standard_normal((n, n))) * 0.02 + np.diag(rng.uniform(0.01, 0.5, n))
+    C = rng.standard_normal((m, n))
+    SR = np.diag(rng.uniform(0.01, 0.1, m))
+    assert rel_err(api.affine_sqrt(ctx, S, C, SR), orc.affine_sqrt(S, C, SR)) <= TOL
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("L,seed", [(3, 12), (50, 1023), (150, 3)])
+def test_affine_bundle_fused_vs_oracle(ctx, gcam, ocam, layout, L, seed):
+    """affineTransform(mu, S, MeasurementPointLandmarkBundle) as at SLAM.cpp:371-387:
+    the fused block-sparse S*C^T path must equal the dense reference formula."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(L, seed)
+    x = sc.x.copy()
+    x[3:6] = [0.02, -0.01, 0.03]
+    muy, Syy, code = api.affine_bundle(ctx, gcam, x, sc.S, layout)
+    h0, SR0, C0, code0 = orc.bundle_measure(x, ocam, layout)
+    Syy0 = orc.affine_sqrt(sc.S, C0, SR0)
+    assert np.array_equal(code, code0) and rel_err(muy, h0) <= TOL
+    assert rel_err(Syy, Syy0) <= TOL
+    # and through the unfused device path: bundle kernel -> dense GEMM -> QR
+    h, SR, C, _ = api.bundle_measure(ctx, gcam, x, layout)
+    assert rel_err(api.affine_sqrt(ctx, sc.S, C, SR), Syy0) <= TOL
+
+
+def test_condition_on_marginal(ctx):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(3)
+    for ny, nx in ((3, 4), (40, 90), (1, 1)):
+        S = np.triu(rng.standard_normal((ny + nx, ny + nx))) + 3 * np.eye(ny + nx)
+        mu, y = rng.standard_normal(ny + nx), rng.standard_normal(ny)
+        m, Sx = api.condition_on_marginal(ctx, mu, S, y)
+        m0, Sx0 = orc.condition_on_marginal(mu, S, y)
+        assert rel_err(m, m0) <= TOL and np.array_equal(Sx, Sx0)
+
+
+def test_iekf_post_sqrt_vs_oracle(ctx):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(8)
+    for n in (3, 40, 162):
+        A = rng.standard_normal((n, n))
+        Hs = A @ A.T + n * np.eye(n)
+        Q, v = orc.sym_eig(Hs)
+        S = api.iekf_post_sqrt(ctx, Q, v)
+        assert rel_err(S, orc.iekf_post_sqrt(Q, v)) <= TOL
+        assert rel_err(S.T @ S, np.linalg.inv(Hs)) <= 1e-8
+
+
+@pytest.mark.parametrize("L,seed", [(2, 5), (50, 1023)])
+def test_cost_joint_density(ctx, gcam, ocam, L, seed):
+    """CostJointDensity (gaussian.hpp:455-466): V = -(logprior + loglik), g, H."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(L, seed)
+    rng = np.random.default_rng(1)
+    x = sc.x + 1e-3 * rng.standard_normal(sc.n)
+    V, g, H = api.cost_joint_density(ctx, gcam, x, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    lp, gp, Hp = orc.log_gaussian(x, sc.x, sc.S)
+    ll, gl, Hl, _ = orc.point_loglik_dual_sparse(x, sc.y, sc.visible, ocam, sc.sigma)
+    assert abs(V + (lp + ll)) <= TOL * abs(lp + ll)
+    assert rel_err(g, -(gp + gl)) <= TOL and rel_err(H, -(Hp + Hl)) <= TOL
+
+
+@pytest.mark.parametrize("L,seed", [(2, 41), (5, 41), (20, 7), (50, 1023)])
+def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed):
+    """measurementUpdateIEKF (gaussian.hpp:469-532) as called at SLAM.cpp:492.  The
+    posterior mean must match the oracle's; the posterior square-root factor is
+    compared through S^T S and |diag S| because its row signs follow the
+    eigenvector signs of the host eigensolver (the reference has the same
+    dependence on Eigen's SelfAdjointEigenSolver)."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(L, seed)
+    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
+    assert ret == 0 and ret0 == 0
+    assert (iters, evals) == (iters0, evals0)
+    scale = np.abs(np.diag(Sp0 @ Sp0.T)) ** 0.5 + 1e-300
+    assert np.max(np.abs(mup - mup0) / np.maximum(np.abs(mup0), sc.diag)) <= 1e-7
+    assert not np.tril(Sp, -1).any()
+    assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-7
+    assert rel_err(np.abs(np.diag(Sp)), np.abs(np.diag(Sp0))) <= 1e-7
+    # the update must not increase the cost and the posterior information matches the Hessian at the optimum
+    V0, _, _ = api.cost_joint_density(ctx, gcam, sc.x, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    V1, g1, H1 = api.cost_joint_density(ctx, gcam, mup, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    assert V1 <= V0
+    assert rel_err(np.linalg.inv(Sp.T @ Sp), H1) <= 1e-6

@@ -1,0 +1,260 @@
+// Host driver of the iterated-EKF measurement update: the trust-region Newton
+// loop and the Moré-Sorensen subproblem stay on the host (as in the reference,
+// src/fmin.hpp:19-107 and src/fmin.cpp:40-131) and drive the device kernels for
+// the cost, gradient, Hessian and the posterior square-root QR
+// (src/gaussian.hpp:469-532).
+//
+// The symmetric eigendecomposition the loop needs (Eigen::SelfAdjointEigenSolver
+// in the reference, src/fmin.hpp:42-44,99-101) is done here by Householder
+// tridiagonalisation + implicit-shift QL on the host; eigenvalues ascending,
+// lower triangle read, like Eigen.
+#include "linalg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+namespace vslam {
+
+
+// Eigen-decomposition of the symmetric matrix whose lower triangle is in H
+// (column-major, n x n).  Q column-major eigenvectors, v ascending eigenvalues.
+void sym_eig_host(const double *H, int n, double *Q, double *v)
+{
+    std::vector<double> a((size_t)n * n), e(n, 0.0), d(n, 0.0);
+    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };     // row-major working copy
+    for (int j = 0; j < n; ++j)
+        for (int i = j; i < n; ++i) { A(i, j) = H[(size_t)j * n + i]; A(j, i) = H[(size_t)j * n + i]; }
+    // --- Householder reduction to tridiagonal form, accumulating the transformation ---
+    for (int i = n - 1; i >= 1; --i) {
+        const int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += std::fabs(A(i, k));
+            if (scale == 0.0) e[i] = A(i, l);
+            else {
+                for (int k = 0; k <= l; ++k) { A(i, k) /= scale; h += A(i, k) * A(i, k); }
+                double f = A(i, l);
+                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                A(i, l) = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    A(j, i) = A(i, j) / h;
+                    g = 0.0;
+                    for (int k = 0; k <= j; ++k) g += A(j, k) * A(i, k);
+                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * A(i, k);
+                    e[j] = g / h;
+                    f += e[j] * A(i, j);
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = A(i, j);
+                    e[j] = g = e[j] - hh * f;
+                    for (int k = 0; k <= j; ++k) A(j, k) -= f * e[k] + g * A(i, k);
+                }
+            }
+        } else e[i] = A(i, l);
+        d[i] = h;
+    }
+    d[0] = 0.0; e[0] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int l = i - 1;
+        if (d[i] != 0.0)
+            for (int j = 0; j <= l; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= l; ++k) g += A(i, k) * A(k, j);
+                for (int k = 0; k <= l; ++k) A(k, j) -= g * A(k, i);
+            }
+        d[i] = A(i, i);
+        A(i, i) = 1.0;
+        for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
+    }
+    // --- implicit-shift QL on the tridiagonal matrix ---
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    const double eps = std::numeric_limits<double>::epsilon();
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= eps * dd) break;
+            }
+            if (m != l) {
+                if (++iter > 200) break;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i], b = c * e[i];
+                    e[i + 1] = r = std::hypot(f, g);
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    for (int k = 0; k < n; ++k) {
+                        f = A(k, i + 1);
+                        A(k, i + 1) = s * A(k, i) + c * f;
+                        A(k, i) = c * A(k, i) - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] < d[y]; });
+    for (int c = 0; c < n; ++c) {
+        v[c] = d[order[c]];
+        for (int k = 0; k < n; ++k) Q[(size_t)c * n + k] = A(k, order[c]);
+    }
+}
+
+static double norm2(const std::vector<double> &a) { double s = 0; for (double t : a) s += t * t; return std::sqrt(s); }
+
+// minimise 0.5 p'Hp + g'p subject to |p| <= D with H = Q diag(v) Q'   (src/fmin.cpp:40-131)
+int trs_host(const double *Q, const double *v, const double *g, int n, double D, std::vector<double> &p)
+{
+    const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
+    const int maxIterations = 20;
+    p.assign(n, 0.0);
+    const double l1 = v[0];
+    std::vector<double> a(n), vlam(n), t(n);
+    for (int j = 0; j < n; ++j) { double s = 0; const double *q = Q + (size_t)j * n; for (int i = 0; i < n; ++i) s += q[i] * g[i]; a[j] = s; }
+    double lam = l1 < 0 ? 1.01 * std::fabs(l1) : 0.0;
+    for (int i = 0; i < n; ++i) vlam[i] = v[i] + lam;
+    auto p_from = [&]() {
+        std::fill(p.begin(), p.end(), 0.0);
+        for (int c = 0; c < n; ++c) { const double w = a[c] / vlam[c]; const double *q = Q + (size_t)c * n; for (int r = 0; r < n; ++r) p[r] -= q[r] * w; }
+    };
+    p_from();
+    const bool hard = std::fabs(a[0]) < eps && l1 < 0;
+    const double pn = norm2(p);
+    if (l1 < 0 || pn > D || std::fabs(lam * (pn - D)) > sqrteps) {
+        if (hard) {
+            std::vector<double> pvec(n, 0.0);
+            double ssq = 0.0;
+            for (int i = 0; i < n; ++i)
+                if (std::fabs(v[i] - l1) > sqrteps) {
+                    const double scv = a[i] / (v[i] - l1);
+                    ssq += scv * scv;
+                    const double *q = Q + (size_t)i * n;
+                    for (int r = 0; r < n; ++r) pvec[r] += q[r] * scv;
+                }
+            const double tt = std::sqrt(D * D - ssq);
+            for (int r = 0; r < n; ++r) p[r] = tt * Q[r] - pvec[r];
+            double pg = 0, quad = 0;
+            for (int r = 0; r < n; ++r) pg += p[r] * g[r];
+            for (int j = 0; j < n; ++j) { double s = 0; const double *q = Q + (size_t)j * n; for (int i = 0; i < n; ++i) s += q[i] * p[i]; quad += s * v[j] * s; }
+            if (pg + 0.5 * quad > 0.0)
+                for (int r = 0; r < n; ++r) p[r] = -tt * Q[r] - pvec[r];
+        } else {
+            int k;
+            for (k = 0; k < maxIterations; ++k) {
+                double ppn2 = 0, dpp = 0;
+                for (int i = 0; i < n; ++i) { const double pp = -a[i] / vlam[i], dp = a[i] / (vlam[i] * vlam[i]); ppn2 += pp * pp; dpp += dp * pp; }
+                const double ppn = std::sqrt(ppn2), ff = 1 / D - 1 / ppn, gg = dpp / (ppn * ppn * ppn);
+                const double lo = std::max(0.0, -l1) + sqrteps * std::max(0.0, -l1);
+                lam = std::max(lo, lam - ff / gg);
+                for (int i = 0; i < n; ++i) vlam[i] = v[i] + lam;
+                if (std::fabs(ff) < sqrteps) break;
+            }
+            p_from();
+            if (k >= maxIterations) return 1;
+        }
+    }
+    return 0;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out);
+
+extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *cam,
+                                                      const double *mu, const double *S, int n, int ldS,
+                                                      const double *y, const uint8_t *visible, double sigma,
+                                                      double *mu_post, double *S_post, int ldSp,
+                                                      int32_t *fmin_code, int32_t *iters, int32_t *cost_evals)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!mu || !S || !y || !visible || !mu_post || !S_post) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf: null pointer");
+    if (n < 15 || (n - 12) % 3 != 0 || ldS < n || ldSp < n) return fail(ctx, VSLAM_ERR_SHAPE, "measurement_update_iekf: n=%d is not 12+3L or ld < n", n);
+    if (!(sigma > 0.0)) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf: sigma must be positive");
+    CamK k;
+    VSLAM_TRY(resolve_camera(ctx, cam, &k));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n)));
+    CostDevice c;
+    cost_carve(ctx->ws, n, &c);
+    hipStream_t s = ctx->stream;
+    const size_t nn = (size_t)n * n;
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.mu, mu, n * 8, hipMemcpyHostToDevice, s));
+    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.y, y, 2 * c.L * 8, hipMemcpyHostToDevice, s));
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.vis, visible, c.L, hipMemcpyHostToDevice, s));
+
+    int evals = 0;
+    auto cost = [&](const std::vector<double> &x, std::vector<double> &g, std::vector<double> &H, double *f) -> vslam_status {
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.x, x.data(), n * 8, hipMemcpyHostToDevice, s));
+        VSLAM_TRY(cost_eval_dev(ctx, k, sigma, &c));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(f, c.vals + 2, 8, hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g.data(), c.g, n * 8, hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H.data(), c.H, nn * 8, hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        ++evals;
+        return VSLAM_OK;
+    };
+
+    // fminNewtonTrustEig, src/fmin.hpp:19-107
+    std::vector<double> x(mu, mu + n), g(n), gn(n), xn(n), p, H(nn), Hn(nn), Q(nn), v(n);
+    double f = 0.0, fn = 0.0;
+    VSLAM_TRY(cost(x, g, H, &f));                                       // :39
+    sym_eig_host(H.data(), n, Q.data(), v.data());                      // :42-44
+    double Delta = 1e0;
+    int ret = 1, it;
+    for (it = 0; it < 50; ++it) {
+        trs_host(Q.data(), v.data(), g.data(), n, Delta, p);            // :52
+        double pg = 0;
+        for (int i = 0; i < n; ++i) pg += p[i] * g[i];
+        const double LambdaSq = -pg;
+        if (std::fabs(LambdaSq) < 2 * std::numeric_limits<double>::epsilon()) { ret = 0; break; }   // :61-67
+        for (int i = 0; i < n; ++i) xn[i] = x[i] + p[i];
+        VSLAM_TRY(cost(xn, gn, Hn, &fn));                               // :72
+        double pHp = 0;
+        for (int cidx = 0; cidx < n; ++cidx) {
+            const double *col = H.data() + (size_t)cidx * n;
+            double sdot = 0;
+            for (int r = 0; r < n; ++r) sdot += p[r] * col[r];
+            pHp += sdot * p[cidx];
+        }
+        const double dm = -pg - 0.5 * pHp, rho = (f - fn) / dm, pn = norm2(p);
+        if (rho < 0.1) Delta = 0.25 * pn;
+        else if (rho > 0.75 && pn > 0.8 * Delta) Delta = 2.0 * Delta;
+        if (rho >= 0.001) {
+            x = xn; f = fn; g = gn; H.swap(Hn);
+            sym_eig_host(H.data(), n, Q.data(), v.data());
+        }
+    }
+    for (int i = 0; i < n; ++i) mu_post[i] = x[i];
+    if (fmin_code) *fmin_code = ret;
+    if (iters) *iters = it;
+    if (cost_evals) *cost_evals = evals;
+    // posterior square-root covariance, src/gaussian.hpp:513-516
+    std::vector<double> Sp(nn);
+    VSLAM_TRY(vslam_iekf_post_sqrt(ctx, Q.data(), v.data(), n, Sp.data()));
+    for (int cidx = 0; cidx < n; ++cidx)
+        for (int r = 0; r < n; ++r) S_post[(size_t)cidx * ldSp + r] = Sp[(size_t)cidx * n + r];
+    return VSLAM_OK;
+}

@@ -47,4 +47,18 @@ vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, do
 // Solves S^T z = b (trans = true) or S z = b (trans = false) for one vector, S upper triangular.
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z);
 
+// Device buffers of one CostJointDensity problem (reference src/gaussian.hpp:435-467),
+// carved out of the context workspace; shared by the cost entry point and the
+// IEKF driver.
+struct CostDevice {
+    int n, L;
+    double *x, *mu, *S, *y, *tmp, *gp, *gl, *g, *Hp, *Hl, *H, *vals;   // vals: [logprior, loglik, V]
+    uint8_t *vis;
+    double *W; void *tws;
+    bool prior_ready;
+};
+size_t cost_ws_bytes(int n);
+void cost_carve(void *ws, int n, CostDevice *c);
+vslam_status cost_eval_dev(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c);
+
 }  // namespace vslam
