@@ -1,0 +1,74 @@
+"""Corner front-end leg of bench.py: 1080p frames/s (Harris + Shi-Tomasi keypoint
+lists per frame: response -> 3x3 NMS -> threshold -> score-sorted top-K)."""
+import time
+
+import numpy as np
+
+W, H = 1920, 1080
+HBM_PEAK_GBS = 8000.0
+
+
+def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
+    import torch
+    import torch.distributed as dist
+    from visualslam_amd import api, synthetic as syn
+
+    F = args.frames
+    base = np.stack([syn.frame(5000 + 8 * rank + i) for i in range(min(F, 8))])
+    frames = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+    tb = torch.tensor(base, device=dev)
+    for i in range(F):
+        frames[i] = torch.roll(tb[i % tb.shape[0]], shifts=(i // tb.shape[0]) * 7, dims=1)   # distinct frames
+    params = api.corner_params(harris_thresh=1e-4, shi_thresh=1e-3, max_features=10000)
+    cap = 10000
+    out = torch.zeros((F, 2, cap, 3), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((F, 2), dtype=torch.int32, device=dev)
+
+    def step():
+        api.corner_detect_batch_dev(ctx, frames, W, H, W, W * H, F, params, api_both, out, cap, cnt)
+
+    api_both = 2
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    counts = cnt.cpu().numpy()
+    assert (counts >= 0).all(), "candidate list overflow"
+    kp = float(counts.sum()) / F
+    alg = (W * H + 12.0 * kp) * F
+    achieved = alg / (dev_ms * 1e-3) / 1e9
+    res = {
+        "metric": "corner-detect frames/s (1080p)", "value": F * args.steps * world / elapsed, "unit": "frames/s",
+        "frames_per_gpu_per_step": F, "ms_per_step": elapsed / args.steps * 1e3,
+        "mean_keypoints_per_frame": {"harris": float(counts[:, 0].mean()), "shi_tomasi": float(counts[:, 1].mean())},
+        "roofline": {"bound": "hbm", "kernel": "corner_tile_kernel<3,false> + sort/merge/emit", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_step": alg, "device_ms_per_step": dev_ms},
+        "dtype": "u8 -> int32 structure tensor -> f32 response",
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc
+        op = orc.corner_params(harris_thresh=1e-4, shi_thresh=1e-3, max_features=10000)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 5.0:
+            orc.corner_detect(base[reps % len(base)], op, 0)
+            orc.corner_detect(base[reps % len(base)], op, 1)
+            reps += 1
+        res["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d synthetic 1080p frames, both detectors, oracle scalar C" % reps}
+    return res

@@ -15,8 +15,10 @@ struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    void *ws = nullptr;          // device workspace, grown on demand
+    void *ws = nullptr;          // device workspace of the entry points, grown on demand
     size_t ws_bytes = 0;
+    void *scratch = nullptr;     // kernel-internal scratch (partial results), separate so that an
+    size_t scratch_bytes = 0;    // entry point's carve-up of `ws` stays valid across launches
     void *pinned = nullptr;      // small pinned host staging buffer
     size_t pinned_bytes = 0;
     char err[512] = {0};
@@ -52,6 +54,7 @@ inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
 // Ensures the context workspace holds at least `bytes`; contents are not kept
 // across a growth.  Synchronises the stream before freeing the old block.
 vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes);
+vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes);
 
 // Carves 256-byte aligned sub-buffers out of the workspace.
 struct Arena {

@@ -18,10 +18,11 @@
 //            descending, then y, then x ascending; first max_features.
 //
 // Kernel 1 (corner_tile_kernel): one workgroup per 64x32 output tile.  The u8
-// tile plus a (block/2+2)-pixel halo is read once from HBM with coalesced row
-// loads into LDS; gradients -> products -> separable window sums -> response
-// -> NMS all stay in LDS.  Survivors are appended (wave-aggregated atomics) to
-// a per-frame candidate list as 64-bit sort keys that encode score, y and x.
+// tile plus a (block/2+2)-pixel halo is read once from HBM with aligned 4-byte
+// row loads into LDS; gradients -> products -> separable running window sums
+// -> response -> NMS all stay in LDS.  Survivors are staged in LDS and appended
+// with one atomic reservation per workgroup to a per-frame candidate list of
+// 64-bit sort keys that encode score, y and x.
 // Kernel 2 (sort_chunk_kernel): bitonic sort of up to 16384 keys in LDS by one
 // 1024-thread workgroup per chunk; kernel 3 merges sorted chunks pairwise
 // keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
@@ -61,84 +62,147 @@ struct CornerArgs {
     uint64_t *cand;        // [frame][det][CAND_CAP]
     int32_t *cand_count;   // [frame][det]
     float *map_h, *map_s;  // dense maps (MAPS mode), single frame
+    int tiles_x, frames;
 };
 
 // DET: bit0 Harris, bit1 Shi-Tomasi.  MAPS: write dense response maps instead of keypoints.
+// grid.x = tiles * frames with the frame index fastest, so the workgroups in
+// flight at any moment belong to many frames and their (one per workgroup and
+// detector) candidate-count atomics spread over many counters.
 template <int DET, bool MAPS>
 __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int lcnt[2], gbase[2];
     const int hb = a.bs >> 1, R = hb + 1;          // response needs image +-R
     const int halo = R + 1;                        // +1 for the NMS ring
     const int IW = TW + 2 * halo, IH = TH + 2 * halo;      // image tile
     const int GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1);  // gradient-product tile (response ring +-hb)
     const int RW = TW + 2, RH = TH + 2;            // response tile
-    // LDS carve-up
-    int32_t *pa = reinterpret_cast<int32_t *>(smem);               // GW*GH   Ix^2   (later: response maps)
-    int32_t *pb = pa + GW * GH;                                    //         Iy^2
-    int32_t *pc = pb + GW * GH;                                    //         IxIy
+    // LDS carve-up (int32 everywhere: exact integer structure tensor)
+    int32_t *pa = reinterpret_cast<int32_t *>(smem);               // GW*GH   Ix^2   (later: Harris map)
+    int32_t *pb = pa + GW * GH;                                    //         Iy^2   (later: Shi-Tomasi map)
+    int32_t *pc = pb + GW * GH;                                    //         IxIy   (later: staged candidates)
     int32_t *ha = pc + GW * GH;                                    // RW*GH   horizontal sums
     int32_t *hbb = ha + RW * GH;
     int32_t *hc = hbb + RW * GH;
-    uint8_t *img = reinterpret_cast<uint8_t *>(hc + RW * GH);      // IW*IH
+    int32_t *img = ha;                                             // IW*IH unpacked pixels, dead before ha is written
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const uint8_t *gray = a.gray + (size_t)blockIdx.z * a.stride_frame;
+    const int frame = blockIdx.x % a.frames, tile = blockIdx.x / a.frames;
+    const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH;
+    const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
     const int w = a.w, h = a.h;
+    if (tid < 2) lcnt[tid] = 0;
 
-    // ---- 1. image tile (clamped reads; clamped pixels only feed invalid outputs) ----
-    for (int i = tid; i < IW * IH; i += 256) {
-        int ly = i / IW, lx = i - ly * IW;
-        int gx = min(max(x0 - halo + lx, 0), w - 1), gy = min(max(y0 - halo + ly, 0), h - 1);
-        img[i] = gray[(size_t)gy * a.stride + gx];
+    // ---- 1. image tile: aligned 4-byte loads, unpacked to int32 (clamped at the image edge;
+    //         clamped pixels only feed outputs that are marked invalid) ----
+    {
+        const int gx0 = x0 - halo, gy0 = y0 - halo;
+        const int ax0 = gx0 & ~3;
+        const int ND = ((gx0 + IW - 1) >> 2) - (ax0 >> 2) + 1;
+        const bool fast_ok = ((a.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+        for (int item = tid; item < ND * IH; item += 256) {
+            const int r = item / ND, d = item - r * ND;
+            const int gy = gy0 + r, gx = ax0 + 4 * d;
+            const int cy = min(max(gy, 0), h - 1);
+            uint32_t word;
+            if (fast_ok && gx >= 0 && gx + 3 < w) word = *reinterpret_cast<const uint32_t *>(gray + (size_t)cy * a.stride + gx);
+            else {
+                word = 0;
+                for (int b = 0; b < 4; ++b) word |= (uint32_t)gray[(size_t)cy * a.stride + min(max(gx + b, 0), w - 1)] << (8 * b);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int lx = gx + b - gx0;
+                if (lx >= 0 && lx < IW) img[r * IW + lx] = (int32_t)((word >> (8 * b)) & 255u);
+            }
+        }
     }
     __syncthreads();
-    // ---- 2. Sobel gradients and their products on the GW x GH tile (image offset +1) ----
-    for (int i = tid; i < GW * GH; i += 256) {
-        int ly = i / GW, lx = i - ly * GW;
-        const uint8_t *r0 = img + ly * IW + lx, *r1 = r0 + IW, *r2 = r1 + IW;
-        int ix = ((int)r0[2] - (int)r0[0]) + 2 * ((int)r1[2] - (int)r1[0]) + ((int)r2[2] - (int)r2[0]);
-        int iy = ((int)r2[0] - (int)r0[0]) + 2 * ((int)r2[1] - (int)r0[1]) + ((int)r2[2] - (int)r0[2]);
-        pa[i] = ix * ix; pb[i] = iy * iy; pc[i] = ix * iy;
+    // ---- 2. Sobel gradients and their products, sliding a 3x3 window along x ----
+    {
+        const int seglen = (GW + 5) / 6;
+        for (int item = tid; item < GH * 6; item += 256) {
+            const int ly = item / 6, sgm = item - ly * 6;
+            const int xb = sgm * seglen, xe = min(GW, xb + seglen);
+            if (xb >= xe) continue;
+            const int32_t *r0 = img + ly * IW + xb, *r1 = r0 + IW, *r2 = r1 + IW;
+            int a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1], c0 = r2[0], c1 = r2[1];
+            for (int lx = xb; lx < xe; ++lx) {
+                const int o = lx - xb + 2;
+                const int a2 = r0[o], b2 = r1[o], c2 = r2[o];
+                const int ix = (a2 - a0) + 2 * (b2 - b0) + (c2 - c0);
+                const int iy = (c0 - a0) + 2 * (c1 - a1) + (c2 - a2);
+                const int p = ly * GW + lx;
+                pa[p] = ix * ix; pb[p] = iy * iy; pc[p] = ix * iy;
+                a0 = a1; a1 = a2; b0 = b1; b1 = b2; c0 = c1; c1 = c2;
+            }
+        }
     }
     __syncthreads();
-    // ---- 3. horizontal window sums: RW x GH ----
-    for (int i = tid; i < RW * GH; i += 256) {
-        int ly = i / RW, lx = i - ly * RW;
-        const int32_t *qa = pa + ly * GW + lx, *qb = pb + ly * GW + lx, *qc = pc + ly * GW + lx;
-        int sa = 0, sb = 0, sc = 0;
-        for (int t = 0; t < a.bs; ++t) { sa += qa[t]; sb += qb[t]; sc += qc[t]; }
-        ha[i] = sa; hbb[i] = sb; hc[i] = sc;
+    // ---- 3. horizontal window sums (running sums; integers, so exact): RW x GH ----
+    {
+        const int seglen = (RW + 5) / 6, bs = a.bs;
+        for (int item = tid; item < GH * 6; item += 256) {
+            const int ly = item / 6, sgm = item - ly * 6;
+            const int xb = sgm * seglen, xe = min(RW, xb + seglen);
+            if (xb >= xe) continue;
+            const int32_t *qa = pa + ly * GW + xb, *qb = pb + ly * GW + xb, *qc = pc + ly * GW + xb;
+            int sa = 0, sb = 0, sc = 0;
+            for (int t = 0; t < bs; ++t) { sa += qa[t]; sb += qb[t]; sc += qc[t]; }
+            int o = ly * RW + xb;
+            ha[o] = sa; hbb[o] = sb; hc[o] = sc;
+            for (int lx = xb + 1; lx < xe; ++lx) {
+                const int in = lx - xb + bs - 1, out = lx - xb - 1;
+                sa += qa[in] - qa[out]; sb += qb[in] - qb[out]; sc += qc[in] - qc[out];
+                ++o;
+                ha[o] = sa; hbb[o] = sb; hc[o] = sc;
+            }
+        }
     }
     __syncthreads();
-    // ---- 4. vertical sums + response: RW x RH, stored over the product buffers ----
+    // ---- 4. vertical running sums + response: RW x RH, stored over the product buffers ----
     float *resp_h = reinterpret_cast<float *>(pa), *resp_s = reinterpret_cast<float *>(pb);
-    for (int i = tid; i < RW * RH; i += 256) {
-        int ly = i / RW, lx = i - ly * RW;
-        int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-        int sa = 0, sb = 0, sc = 0;
-        for (int t = 0; t < a.bs; ++t) { sa += ha[(ly + t) * RW + lx]; sb += hbb[(ly + t) * RW + lx]; sc += hc[(ly + t) * RW + lx]; }
-        bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
-        float fa = (float)sa, fb = (float)sb, fc = (float)sc;
-        float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
-        if (DET & 1) {
-            float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
-            float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
-            resp_h[i] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
-        }
-        if (DET & 2) {
-            float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
-            // correctly rounded float sqrt via fp64 (53 >= 2*24+2 bits: the double rounding is exact)
-            float root = (float)sqrt((double)__fadd_rn(__fmul_rn(d, d), t2));
-            resp_s[i] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+    {
+        const int vlen = (RH + 2) / 3, bs = a.bs;
+        for (int item = tid; item < RW * 3; item += 256) {
+            const int sgm = item / RW, lx = item - sgm * RW;
+            const int yb = sgm * vlen, ye = min(RH, yb + vlen);
+            int sa = 0, sb = 0, sc = 0;
+            for (int t = 0; t < bs; ++t) { const int q = (yb + t) * RW + lx; sa += ha[q]; sb += hbb[q]; sc += hc[q]; }
+            const int gx = x0 - 1 + lx;
+            for (int ly = yb; ly < ye; ++ly) {
+                if (ly > yb) {
+                    const int in = (ly + bs - 1) * RW + lx, out = (ly - 1) * RW + lx;
+                    sa += ha[in] - ha[out]; sb += hbb[in] - hbb[out]; sc += hc[in] - hc[out];
+                }
+                const int gy = y0 - 1 + ly;
+                const bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
+                const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
+                const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
+                const int i = ly * RW + lx;
+                if (DET & 1) {
+                    const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
+                    const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
+                    resp_h[i] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
+                }
+                if (DET & 2) {
+                    const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
+                    // correctly rounded float sqrt via fp64 (53 >= 2*24+2 bits: the double rounding is exact)
+                    const float root = (float)sqrt((double)__fadd_rn(__fmul_rn(d, d), t2));
+                    resp_s[i] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+                }
+            }
         }
     }
     __syncthreads();
-    // ---- 5. maps, or NMS + threshold + append ----
+    // ---- 5. maps, or NMS + threshold; survivors staged in LDS ----
+    uint64_t *stage = reinterpret_cast<uint64_t *>(pc);            // [2][TW*TH/4]: 3x3 NMS keeps <= 1 pixel per 2x2
+    constexpr int STAGE_CAP = TW * TH / 4;
     for (int i = tid; i < TW * TH; i += 256) {
-        int ly = i / TW, lx = i - ly * TW;
-        int gx = x0 + lx, gy = y0 + ly;
+        const int ly = i >> 6, lx = i & 63;
+        const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= w || gy >= h) continue;
         const int c = (ly + 1) * RW + (lx + 1);
         if (MAPS) {
@@ -152,14 +216,29 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
             if (!(DET & (1 << det))) continue;
             const float *rp = det == 0 ? resp_h : resp_s;
             const float thr = det == 0 ? a.thr_h : a.thr_s;
-            float r = rp[c];
+            const float r = rp[c];
             if (!(r > thr)) continue;
-            bool ok = r > rp[c - RW - 1] && r > rp[c - RW] && r > rp[c - RW + 1] && r > rp[c - 1] &&
-                      r >= rp[c + 1] && r >= rp[c + RW - 1] && r >= rp[c + RW] && r >= rp[c + RW + 1];
+            const bool ok = r > rp[c - RW - 1] && r > rp[c - RW] && r > rp[c - RW + 1] && r > rp[c - 1] &&
+                            r >= rp[c + 1] && r >= rp[c + RW - 1] && r >= rp[c + RW] && r >= rp[c + RW + 1];
             if (!ok) continue;
-            int32_t *cnt = a.cand_count + ((size_t)blockIdx.z * 2 + det);
-            int slot = atomicAdd(cnt, 1);
-            if (slot < CAND_CAP) a.cand[((size_t)blockIdx.z * 2 + det) * CAND_CAP + slot] = make_key(r, gx, gy);
+            const int slot = atomicAdd(&lcnt[det], 1);
+            if (slot < STAGE_CAP) stage[det * STAGE_CAP + slot] = make_key(r, gx, gy);
+        }
+    }
+    if (MAPS) return;
+    __syncthreads();
+    // ---- 6. one global reservation per workgroup and detector, then a coalesced copy ----
+    if (tid < 2 && (DET & (1 << tid)) && lcnt[tid] > 0)
+        gbase[tid] = atomicAdd(a.cand_count + ((size_t)frame * 2 + tid), min(lcnt[tid], STAGE_CAP));
+    __syncthreads();
+#pragma unroll
+    for (int det = 0; det < 2; ++det) {
+        if (!(DET & (1 << det))) continue;
+        const int cnt = min(lcnt[det], STAGE_CAP);
+        uint64_t *dst = a.cand + ((size_t)frame * 2 + det) * CAND_CAP;
+        for (int i = tid; i < cnt; i += 256) {
+            const int pos = gbase[det] + i;
+            if (pos < CAND_CAP) dst[pos] = stage[det * STAGE_CAP + i];
         }
     }
 }
@@ -252,7 +331,8 @@ static size_t tile_lds_bytes(int bs)
 {
     const int hb = bs / 2, halo = hb + 2;
     const int IW = TW + 2 * halo, IH = TH + 2 * halo, GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1), RW = TW + 2;
-    size_t b = (size_t)GW * GH * 4 * 3 + (size_t)RW * GH * 4 * 3 + (size_t)IW * IH;
+    size_t sums = (size_t)RW * GH * 4 * 3, imgb = (size_t)IW * IH * 4;     // the image tile overlays the sums
+    size_t b = (size_t)GW * GH * 4 * 3 + (sums > imgb ? sums : imgb);
     return (b + 15) & ~size_t(15);
 }
 
@@ -293,7 +373,8 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     a.cand_count = ar.take<int32_t>((size_t)frames * 2);
     hipStream_t s = ctx->stream;
     VSLAM_HIP_TRY(ctx, hipMemsetAsync(a.cand_count, 0, (size_t)frames * 2 * 4, s));
-    dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH, frames);
+    a.tiles_x = (a.w + TW - 1) / TW; a.frames = frames;
+    dim3 grid((unsigned)((size_t)a.tiles_x * ((a.h + TH - 1) / TH) * frames));
     size_t lds = tile_lds_bytes(a.bs);
     const int det_mask = detector == 2 ? 3 : (1 << detector);
     if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false>), grid, dim3(256), lds, s, a);
@@ -397,7 +478,8 @@ extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gra
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dimg, gray, img_bytes, hipMemcpyHostToDevice, s));
     CornerArgs a = make_args(dimg, w, h, stride, 0, params);
     a.map_h = dh; a.map_s = ds;
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, 1);
+    a.tiles_x = (w + TW - 1) / TW; a.frames = 1;
+    dim3 grid((unsigned)(a.tiles_x * ((h + TH - 1) / TH)));
     hipLaunchKernelGGL((corner_tile_kernel<3, true>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     if (harris) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(harris, dh, map_bytes, hipMemcpyDeviceToHost, s));

@@ -27,6 +27,23 @@ vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes)
     return VSLAM_OK;
 }
 
+vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->scratch) {
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        VSLAM_HIP_TRY(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2) + (1u << 16);
+    hipError_t e = hipMalloc(&ctx->scratch, want);
+    if (e != hipSuccess) return fail(ctx, VSLAM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->scratch_bytes = want;
+    return VSLAM_OK;
+}
+
 vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *k)
 {
     const int RATIONAL = 0x4000, THIN = 0x8000;
@@ -116,6 +133,7 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

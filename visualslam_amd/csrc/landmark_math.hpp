@@ -46,6 +46,21 @@ VSLAM_DEV Pose make_pose(const double *eta)
     return p;
 }
 
+// Same, with the three sincos evaluated by lanes 0..2 of the wavefront in parallel
+// and broadcast: a third of the dependent-instruction chain.  All 64 lanes must call.
+VSLAM_DEV Pose make_pose_wave(const double *eta)
+{
+    const int lane = threadIdx.x & 63;
+    double s = 0.0, c = 0.0;
+    if (lane < 3) sincos(eta[3 + lane], &s, &c);
+    Pose p;
+    p.c[0] = eta[0]; p.c[1] = eta[1]; p.c[2] = eta[2];
+    p.sp = __shfl(s, 0, 64); p.cp = __shfl(c, 0, 64);
+    p.st = __shfl(s, 1, 64); p.ct = __shfl(c, 1, 64);
+    p.ss = __shfl(s, 2, 64); p.cs = __shfl(c, 2, 64);
+    return p;
+}
+
 // cos/sin of (angle + K*90deg): the K-th derivative of a plane rotation.
 template <int K> VSLAM_DEV void ord(double c, double s, double &ck, double &sk)
 {

@@ -14,12 +14,15 @@
 //            a wavefront butterfly + a fixed-order LDS pass.  It also writes
 //            the all-zero velocity columns 0..5.
 //   block p  "landmark panel": P consecutive landmarks = 3P columns of H.
-//            Streams zeros over its column range with 16-byte stores (H is
-//            >97 % zeros and must be fully written: the reference's callee
-//            resizes and fills the output), then one lane per landmark
-//            re-evaluates that landmark with the same instruction sequence
-//            (so H comes out exactly symmetric) and drops the 6x3 cross block
-//            and the 3x3 diagonal block into place.
+//            One lane per landmark re-evaluates that landmark with the same
+//            instruction sequence as block 0 (so H comes out exactly
+//            symmetric) and parks its 6x3 cross block and 3x3 diagonal block
+//            in LDS; then the whole block streams the 3P columns to HBM in
+//            row order, 512 contiguous bytes per wavefront store, selecting
+//            the parked values on the 9 non-zero rows of each column and zero
+//            elsewhere (H is >97 % zeros but is a dense output: the
+//            reference's callee resizes and fills it).  No cache line is
+//            written twice or partially, except at panel edges.
 // The kernel is HBM-write bound: 8 n^2 bytes of H per instance.
 #include "landmark_math.hpp"
 
@@ -68,6 +71,7 @@ __device__ __forceinline__ void block_zero_cols(double *H, int ldH, int n, int c
 template <int ORDER>
 __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, LoglikArgs a)
 {
+    extern __shared__ double vals[];                   // [P][3 columns][9 rows] parked non-zeros of a landmark panel
     const int b = blockIdx.y, tid = threadIdx.x;
     const double *x = a.x + (size_t)b * a.sx;
     const double *y = a.y + (size_t)b * a.sy;
@@ -81,20 +85,14 @@ __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, Loglik
     if (is_cam) { jb = 0; je = L; }
     else { jb = (blockIdx.x - 1) * a.P; je = min(L, jb + a.P); }
 
-    if (ORDER >= 2) {
-        if (is_cam) block_zero_cols(H, ldH, n, 0, 6);
-        else {
-            block_zero_cols(H, ldH, n, 12 + 3 * jb, 12 + 3 * je);
-            __syncthreads();   // zeros are ordered before this block's value stores
-        }
-    }
+    if (ORDER >= 2 && is_cam) block_zero_cols(H, ldH, n, 0, 6);
 
     double acc[28];
 #pragma unroll
     for (int i = 0; i < 28; ++i) acc[i] = 0.0;
 
-    if (jb + tid < je) {
-        const Pose pose = make_pose(x + 6);
+    if (jb + (tid & ~63) < je) {                       // wave-uniform: whole wavefronts enter
+        const Pose pose = make_pose_wave(x + 6);
         for (int j = jb + tid; j < je; j += kThreads) {
             Terms t;
             landmark_terms<ORDER>(cam, pose, x + 12 + 3 * j, y + 2 * j, vis[j] != 0, a.is2, a.lconst, t);
@@ -112,6 +110,7 @@ __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, Loglik
 #pragma unroll
                     for (int i = 0; i < 9; ++i) acc[13 + i] += t.E[i];
                     // rows 12+3j.. of the pose columns: H[r_i][c_a] = -N[i][a], H[r_i][Theta_k] = E[i][k]
+                    // (3 consecutive doubles per lane, consecutive lanes adjacent: contiguous stores)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         double *col = H + (size_t)(6 + c) * ldH + 12 + 3 * j;
@@ -121,18 +120,34 @@ __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, Loglik
                     }
                 }
             } else if (ORDER >= 2) {
-                // landmark columns 12+3j+i: rows 6..8 = -N[:,i], rows 9..11 = E[i][:], rows 12+3j.. = N[:,i]
+                // column 12+3j+i: rows 6..8 = -N[:,i], rows 9..11 = E[i][:], rows 12+3j.. = N[:,i]
+                double *v = vals + (size_t)(j - jb) * 27;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    double *col = H + (size_t)(12 + 3 * j + i) * ldH;
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        col[6 + r] = -Nf[r][i];
-                        col[9 + r] = t.E[i * 3 + r];
-                        col[12 + 3 * j + r] = Nf[r][i];
+                        v[i * 9 + r] = -Nf[r][i];
+                        v[i * 9 + 3 + r] = t.E[i * 3 + r];
+                        v[i * 9 + 6 + r] = Nf[r][i];
                     }
-                }
             }
+        }
+    }
+    if (ORDER >= 2 && !is_cam) {
+        __syncthreads();
+        // stream the panel: flat index over (column, row), one double per lane per store
+        const int ncol = 3 * (je - jb), c0 = 12 + 3 * jb;
+        int col = 0, row = tid;
+        while (row >= n) { row -= n; ++col; }
+        while (col < ncol) {
+            const int jl = col / 3, d0 = 12 + 3 * (jb + jl);
+            const double *v = vals + (size_t)col * 9;           // == jl*27 + (col%3)*9
+            double out = 0.0;
+            if (row >= 6 && row < 12) out = v[row - 6];
+            else if (row >= d0 && row < d0 + 3) out = v[6 + row - d0];
+            H[(size_t)(c0 + col) * ldH + row] = out;
+            row += kThreads;
+            while (row >= n) { row -= n; ++col; }
         }
     }
     if (!is_cam) return;
@@ -173,6 +188,190 @@ __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, Loglik
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two-launch form for large outputs.  In the fused kernel every workgroup first
+// evaluates its landmarks (a ~5 us dependent fp64 chain at 250 VGPRs, two
+// workgroups per CU) and only then streams, and co-resident workgroups do so in
+// phase, so the store pipes idle during every evaluation.  Here a small kernel
+// evaluates all landmarks once (N and E blocks to a structure-of-arrays record,
+// pose sums reduced per block), and a low-register streaming kernel at full
+// occupancy assembles H from the records.
+// ---------------------------------------------------------------------------
+constexpr int kRecFields = 15;        // N[6] then E[9]
+
+struct TermsArgs {
+    LoglikArgs a;
+    double *rec;       // [batch][kRecFields][L]
+    double *part;      // [batch][nblk][28]
+    int nblk;
+};
+
+__global__ __launch_bounds__(kThreads) void loglik_terms_kernel(CamK cam, TermsArgs t)
+{
+    const LoglikArgs &a = t.a;
+    const int b = blockIdx.y, tid = threadIdx.x, L = a.L;
+    const double *x = a.x + (size_t)b * a.sx;
+    const double *y = a.y + (size_t)b * a.sy;
+    const uint8_t *vis = a.vis + (size_t)b * a.sv;
+    double *g = a.g + (size_t)b * a.sg;
+    double *rec = t.rec + (size_t)b * kRecFields * L;
+    const int j = blockIdx.x * kThreads + tid;
+    double acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+    if (blockIdx.x * kThreads + (tid & ~63) < L) {
+        const Pose pose = make_pose_wave(x + 6);
+        if (j < L) {
+            Terms tm;
+            landmark_terms<2>(cam, pose, x + 12 + 3 * j, y + 2 * j, vis[j] != 0, a.is2, a.lconst, tm);
+            acc[0] = tm.ell;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { acc[1 + i] = tm.gr[i]; acc[4 + i] = tm.gT[i]; g[12 + 3 * j + i] = tm.gr[i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { acc[7 + i] = tm.N[i]; acc[22 + i] = tm.F[i]; rec[(size_t)i * L + j] = tm.N[i]; }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { acc[13 + i] = tm.E[i]; rec[(size_t)(6 + i) * L + j] = tm.E[i]; }
+            if (a.code) a.code[(size_t)b * L + j] = tm.code;
+        }
+    }
+    __shared__ double red[kThreads / 64][28];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) acc[i] = wave_sum(acc[i]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 28; ++i) red[tid >> 6][i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 28) t.part[((size_t)b * t.nblk + blockIdx.x) * 28 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+// value of H[row][column 12+3j+i] on its non-zero rows, from the records
+__device__ __forceinline__ double rec_N(const double *rec, int L, int j, int r, int c)
+{
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int f = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);      // xx xy xz yy yz zz
+    return rec[(size_t)f * L + j];
+}
+
+// Streaming assembly of H from the records.  H (n x n, ld == n) is treated as a flat
+// array; each workgroup owns one 32 KB slice whose boundaries fall on 128-byte lines of
+// the absolute address, and writes it with 16-byte stores in address order, so every
+// cache line is written whole by one wavefront store (partial-line writes cost a
+// read-modify-write at the memory side) and the workgroups in flight cover one compact
+// window of HBM.  An element is zero unless it lies in a pose column (6..11) or on one
+// of the 9 non-zero rows of a landmark column; only those take the lookup path.
+constexpr int kSliceBytes = 32768;
+
+// srec: LDS copy of the records of landmarks j_lo.. (field-major, stride kRecFields per landmark)
+__device__ __forceinline__ double srec_N(const double *srec, int jl, int r, int c)
+{
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    return srec[jl * kRecFields + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5))];
+}
+
+__device__ __forceinline__ double assemble_value(const TermsArgs &t, const double *rec, const double *part_b,
+                                                 const double *srec, int j_lo, int col, int row)
+{
+    const int L = t.a.L;
+    if (col < 6 || row < 6) return 0.0;
+    if (col < 12) {
+        const int c = col - 6;
+        if (row >= 12) {                               // H[r_i][pose c]
+            const int j = (row - 12) / 3, i = (row - 12) - 3 * j;
+            return c < 3 ? -rec_N(rec, L, j, i, c) : rec[(size_t)(6 + i * 3 + (c - 3)) * L + j];
+        }
+        const int rr = row - 6;                        // 6x6 pose block: sums over all landmarks
+        int f; double sgn = 1.0;
+        if (c < 3 && rr < 3) { const int lo = min(rr, c), hi = max(rr, c); f = 7 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); }
+        else if (c >= 3 && rr >= 3) { const int lo = min(rr, c) - 3, hi = max(rr, c) - 3; f = 22 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); }
+        else if (c < 3) { f = 13 + c * 3 + (rr - 3); sgn = -1.0; }
+        else { f = 13 + rr * 3 + (c - 3); sgn = -1.0; }
+        double s = 0.0;
+        for (int k = 0; k < t.nblk; ++k) s += part_b[(size_t)k * 28 + f];
+        return sgn * s;
+    }
+    const int j = (col - 12) / 3, i = (col - 12) - 3 * j, d0 = 12 + 3 * j, jl = j - j_lo;
+    if (row < 9) return -srec_N(srec, jl, row - 6, i);                          // H[c_r][r_i]
+    if (row < 12) return srec[jl * kRecFields + 6 + i * 3 + (row - 9)];         // H[Theta_r][r_i] = E[i][r]
+    if (row >= d0 && row < d0 + 3) return srec_N(srec, jl, row - d0, i);
+    return 0.0;
+}
+
+__device__ __forceinline__ bool assemble_special(int col, int row, int n)
+{
+    if (col < 6 || row < 6) return false;
+    if (col < 12 || row < 12) return true;
+    const int d0 = 12 + 3 * ((col - 12) / 3);
+    return row >= d0 && row < d0 + 3;
+}
+
+__global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
+{
+    extern __shared__ double srec[];                   // records of the landmarks whose columns this slice touches
+    const LoglikArgs &a = t.a;
+    const int b = blockIdx.y, tid = threadIdx.x, n = a.n, L = a.L;
+    double *H = a.H + (size_t)b * a.sH;
+    const double *rec = t.rec + (size_t)b * kRecFields * L;
+    const double *part_b = t.part + (size_t)b * t.nblk * 28;
+    if (blockIdx.x == 0 && tid < 13) {
+        // value and the pose part of the gradient (landmark entries were written by the terms kernel)
+        double *g = a.g + (size_t)b * a.sg;
+        const int f = tid == 12 ? 0 : (tid < 6 ? 0 : (tid < 9 ? 1 + (tid - 6) : 4 + (tid - 9)));
+        double s = 0.0;
+        for (int k = 0; k < t.nblk; ++k) s += part_b[(size_t)k * 28 + f];
+        if (tid == 12) a.value[b] = s;
+        else g[tid] = tid < 6 ? 0.0 : (tid < 9 ? -s : s);
+    }
+    // this block's slice of the flat element range [0, n*n), cut at absolute 128-byte lines
+    const size_t total = (size_t)n * n;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(H);
+    const uintptr_t line0 = base & ~uintptr_t(127);
+    const uintptr_t lo = line0 + (uintptr_t)blockIdx.x * kSliceBytes, hi = lo + kSliceBytes;
+    size_t e0 = lo <= base ? 0 : (size_t)((lo - base) >> 3);
+    size_t e1 = hi <= base ? 0 : (size_t)((hi - base) >> 3);
+    if (e1 > total) e1 = total;
+    if (e0 >= e1) return;
+    int j_lo = 0;
+    {
+        const int cA = (int)(e0 / n), cB = (int)((e1 - 1) / n);
+        if (cB >= 12) {
+            j_lo = cA >= 12 ? (cA - 12) / 3 : 0;
+            const int j_hi = (cB - 12) / 3;
+            for (int q = tid; q < (j_hi - j_lo + 1) * kRecFields; q += kThreads) {
+                const int jl = q / kRecFields, f = q - jl * kRecFields;
+                srec[q] = rec[(size_t)f * L + j_lo + jl];
+            }
+        }
+        __syncthreads();
+    }
+    // head single if the slice starts on an odd 8-byte boundary (only possible at the instance start)
+    size_t e = e0;
+    if ((base + (e << 3)) & 8) {
+        if (tid == 0) { const int col = (int)(e / n), row = (int)(e - (size_t)col * n); H[e] = assemble_value(t, rec, part_b, srec, j_lo, col, row); }
+        ++e;
+    }
+    const size_t npair = (e1 - e) >> 1;
+    size_t idx = e + 2 * (size_t)tid;
+    int col = (int)(idx / n), row = (int)(idx - (size_t)col * n);
+    for (size_t k = tid; k < npair; k += kThreads) {
+        int col2 = col, row2 = row + 1;
+        if (row2 == n) { row2 = 0; ++col2; }
+        double2 o = make_double2(0.0, 0.0);
+        if (assemble_special(col, row, n) || assemble_special(col2, row2, n)) {
+            o.x = assemble_value(t, rec, part_b, srec, j_lo, col, row);
+            o.y = assemble_value(t, rec, part_b, srec, j_lo, col2, row2);
+        }
+        *reinterpret_cast<double2 *>(H + e + 2 * k) = o;
+        row += 2 * kThreads;
+        while (row >= n) { row -= n; ++col; }
+    }
+    if (((e1 - e) & 1) && tid == 0) {                  // tail single (only at the instance end)
+        const size_t el = e1 - 1;
+        const int c = (int)(el / n), r = (int)(el - (size_t)c * n);
+        H[el] = assemble_value(t, rec, part_b, srec, j_lo, c, r);
+    }
+}
+
 static int pick_panel(int L, int batch)
 {
     // aim for a few thousand workgroups so all 256 CUs stream stores
@@ -204,9 +403,23 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
     a.lconst = -std::log(2.0 * 3.14159265358979323846264338327950288) - 2.0 * std::log(sigma);
     const int panels = (a.L + a.P - 1) / a.P;
     dim3 block(kThreads);
-    if (H) {
+    const bool two_launch = H && ldH == n && (size_t)batch * n * n * 8 >= ((size_t)32 << 20);
+    if (two_launch) {
+        const int slices = (int)(((size_t)n * n * 8 + 127 + kSliceBytes - 1) / kSliceBytes) + 1;
+        TermsArgs t;
+        t.a = a;
+        t.nblk = (a.L + kThreads - 1) / kThreads;
+        const size_t rec_doubles = (size_t)batch * kRecFields * a.L, part_doubles = (size_t)batch * t.nblk * 28;
+        VSLAM_TRY(scratch_reserve(ctx, Arena::pad(rec_doubles * 8) + Arena::pad(part_doubles * 8)));
+        Arena ar(ctx->scratch);
+        t.rec = ar.take<double>(rec_doubles);
+        t.part = ar.take<double>(part_doubles);
+        hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), block, 0, ctx->stream, cam, t);
+        const size_t lds = (size_t)((kSliceBytes / 8) / (3 * n) + 3) * kRecFields * sizeof(double);
+        hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), block, lds, ctx->stream, t);
+    } else if (H) {
         dim3 grid(1 + panels, batch);
-        hipLaunchKernelGGL(point_loglik_kernel<2>, grid, block, 0, ctx->stream, cam, a);
+        hipLaunchKernelGGL(point_loglik_kernel<2>, grid, block, (size_t)a.P * 27 * sizeof(double), ctx->stream, cam, a);
     } else if (g) {
         hipLaunchKernelGGL(point_loglik_kernel<1>, dim3(1, batch), block, 0, ctx->stream, cam, a);
     } else {
