@@ -102,9 +102,9 @@ def main():
     import torch.distributed as dist
     from visualslam_amd import api, synthetic as syn
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from visualslam_amd import sharding
+    lay = sharding.RankLayout.from_env()
+    rank, local_rank, world = lay.rank, lay.local_rank, lay.world
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -121,7 +121,7 @@ def main():
 
     B, n, L = args.instances, N_STATE, L_LANDMARKS
     uniq = min(B, 32)
-    xs, ys, vs = build_scenes(uniq, 9000 + 4096 * rank)
+    xs, ys, vs = build_scenes(uniq, sharding.instance_seed(9000, rank, 0))
     reps = (B + uniq - 1) // uniq
     rng = np.random.default_rng(77 + rank)
     x_np = np.tile(xs, (reps, 1))[:B] + 1e-3 * rng.standard_normal((B, n))   # distinct instances
@@ -152,10 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)
 
     # single-instance latency of the same update (launch-latency bound; reported, not the headline)
     x1, y1, v1 = x[:1], y[:1], vis[:1]
@@ -196,7 +193,7 @@ def main():
                                    % (B, B),
                        "instances_per_gpu": B, "landmarks": L, "state_dim": n, "sigma_px": SIGMA,
                        "parallelism": "replicated instances, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "point_loglik_kernel<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "loglik_terms_kernel + loglik_assemble_kernel (one point_loglik call)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
             "single_instance_latency_us": single_us,

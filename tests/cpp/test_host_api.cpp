@@ -1,0 +1,279 @@
+// Exercises the C++ host mirror (visualslam_amd/host/vslam_host.hpp) the way the
+// reference's Catch2 suite exercises its own functors: the known-answer cases of
+// test/src/logGaussian.cpp:10-155 and test/src/affineTransform.cpp:7-136, the
+// arity consistency checks of test/src/measurementModel.cpp, and a full
+// measurementUpdateIEKF call as at src/SLAM.cpp:492.  Needs a gfx950 GPU.
+//
+// usage: test_host_api <camera.xml>     exit code = number of failed checks
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "../../visualslam_amd/host/vslam_host.hpp"
+
+using namespace vslam_host;
+
+static int failures = 0, checks = 0;
+#define CHECK_NEAR(a, b, tol)                                                                          \
+    do {                                                                                               \
+        ++checks;                                                                                      \
+        double a_ = (a), b_ = (b), t_ = (tol);                                                         \
+        if (!(std::fabs(a_ - b_) <= t_ * (1.0 + std::fabs(b_)))) {                                     \
+            ++failures;                                                                                \
+            std::printf("FAIL %s:%d  %s = %.15g, expected %.15g\n", __FILE__, __LINE__, #a, a_, b_);   \
+        }                                                                                              \
+    } while (0)
+#define CHECK_TRUE(c)                                                            \
+    do {                                                                         \
+        ++checks;                                                                \
+        if (!(c)) { ++failures; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #c); } \
+    } while (0)
+
+// Polar-coordinate measurement functor with the published answers of the reference's affineTransform test.
+struct Polar {
+    void operator()(const Vector &x, Vector &f, Matrix &SR, Matrix &J) const
+    {
+        const double pi = 3.14159265358979323846;
+        double r2 = x(0) * x(0) + x(1) * x(1), r = std::sqrt(r2);
+        f.resize(2);
+        f(0) = std::atan2(x(0), x(1));
+        f(1) = r;
+        SR.resize(2, 2);
+        SR(0, 0) = pi / 180.0;
+        SR(1, 1) = 0.1;
+        J.resize(2, 2);
+        J(0, 0) = x(1) / r2;  J(0, 1) = -x(0) / r2;
+        J(1, 0) = x(0) / r;   J(1, 1) = x(1) / r;
+    }
+};
+
+static void test_log_gaussian()
+{
+    Vector x{1, 2, 3}, mu{2, 4, 6}, g;
+    Matrix S(3, 3), H;
+    S(0, 0) = 1; S(1, 1) = 2; S(2, 2) = 3;
+    CHECK_NEAR(logGaussian(x, mu, S), -6.04857506884207, 1e-12);
+    CHECK_NEAR(logGaussian(x, mu, S, g), -6.04857506884207, 1e-12);
+    CHECK_TRUE(g.rows() == 3 && g.cols() == 1);
+    CHECK_NEAR(g(0), 1.0, 1e-12); CHECK_NEAR(g(1), 0.5, 1e-12); CHECK_NEAR(g(2), 1.0 / 3.0, 1e-12);
+    CHECK_NEAR(logGaussian(x, mu, S, g, H), -6.04857506884207, 1e-12);
+    CHECK_TRUE(H.rows() == 3 && H.cols() == 3);
+    CHECK_NEAR(H(0, 0), -1.0, 1e-12); CHECK_NEAR(H(1, 1), -0.25, 1e-12); CHECK_NEAR(H(2, 2), -1.0 / 9.0, 1e-12);
+    CHECK_NEAR(H(0, 1), 0.0, 1e-12); CHECK_NEAR(H(2, 0), 0.0, 1e-12);
+}
+
+static void test_affine_transform()
+{
+    {
+        Vector mux{1, 3}, muy; Matrix Sxx(2, 2), Syy;
+        Sxx(0, 0) = 10; Sxx(1, 1) = 1;
+        affineTransform(mux, Sxx, Polar(), muy, Syy);
+        CHECK_TRUE(muy.rows() == 2 && Syy.rows() == 2 && Syy.cols() == 2);
+        CHECK_NEAR(muy(0), 0.321750554397, 1e-10); CHECK_NEAR(muy(1), 3.16227766017, 1e-10);
+        CHECK_NEAR(Syy(0, 0), -3.00171694492, 1e-10); CHECK_NEAR(Syy(1, 0), 0.0, 1e-12);
+        CHECK_NEAR(Syy(0, 1), -3.12886418774, 1e-10); CHECK_NEAR(Syy(1, 1), -1.05839921328, 1e-10);
+    }
+    {
+        Vector mux{1, 1}, muy; Matrix Sxx(2, 2), Syy;
+        Sxx(0, 0) = 1.5; Sxx(1, 1) = 1.8;
+        affineTransform(mux, Sxx, Polar(), muy, Syy);
+        CHECK_NEAR(muy(0), 0.785398163397, 1e-10); CHECK_NEAR(muy(1), 1.41421356237, 1e-10);
+        CHECK_NEAR(Syy(0, 0), -1.17166745172, 1e-10); CHECK_NEAR(Syy(1, 0), 0.0, 1e-12);
+        CHECK_NEAR(Syy(0, 1), 0.298734812658, 1e-10); CHECK_NEAR(Syy(1, 1), -1.63271476741, 1e-10);
+    }
+}
+
+// A camera 2 m behind a fronto-parallel cloud of landmarks; measurements = projections + noise.
+struct Scene {
+    SlamParameters param;
+    Vector x, mu;
+    Matrix S;
+    Scene(const std::string &xml, int L, unsigned seed)
+    {
+        importCalibrationData(xml, param.camera_param);
+        param.measurement_noise = 7.0;
+        const int n = 12 + 3 * L;
+        std::mt19937 rng(seed);
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        std::normal_distribution<double> N01(0.0, 1.0);
+        x.resize(n);
+        for (int i = 0; i < 6; ++i) x(i) = 0.01 * U(rng);
+        x(6) = 0.05 * U(rng); x(7) = 0.05 * U(rng); x(8) = 0.05 * U(rng);
+        x(9) = 0.02 * U(rng); x(10) = 0.02 * U(rng); x(11) = 0.02 * U(rng);
+        // Camera z axis is the optical axis; with near-zero angles it is the world z axis.
+        for (int j = 0; j < L; ++j) {
+            x(12 + 3 * j) = 0.8 * U(rng);
+            x(13 + 3 * j) = 0.5 * U(rng);
+            x(14 + 3 * j) = 2.0 + 0.5 * U(rng);
+        }
+        MeasurementPointLandmarkBundle h;
+        Vector y;
+        h(x, param.camera_param, y);
+        param.landmarks.resize((size_t)L);
+        for (int j = 0; j < L; ++j) {
+            param.landmarks[(size_t)j].isVisible = (j % 5) != 4;
+            param.landmarks[(size_t)j].pixel_measurement[0] = y(2 * j) + 3.0 * N01(rng);
+            param.landmarks[(size_t)j].pixel_measurement[1] = y(2 * j + 1) + 3.0 * N01(rng);
+        }
+        mu = x;
+        for (int i = 6; i < n; ++i) mu(i) += 0.01 * N01(rng);
+        S.resize(n, n);
+        for (int i = 0; i < n; ++i) {
+            S(i, i) = i < 12 ? 0.05 : 0.2;
+            for (int j = i + 1; j < n; ++j) S(i, j) = 0.002 * U(rng);
+        }
+    }
+};
+
+static void test_measurement_model(const std::string &xml)
+{
+    Scene sc(xml, 6, 3);
+    const int n = sc.x.rows();
+    MeasurementPointLandmarkBundle hb;
+    MeasurementPointLandmarkSingle hs;
+    Vector yb1, yb2, yb3, y1, y2, y3;
+    Matrix SRb2, SRb3, C, SR2, SR3, J;
+    hb(sc.x, sc.param.camera_param, yb1);
+    hb(sc.x, sc.param.camera_param, yb2, SRb2);
+    hb(sc.x, sc.param.camera_param, yb3, SRb3, C);
+    CHECK_TRUE(yb1.rows() == 12 && SRb2.rows() == 12 && SRb2.cols() == 12 && C.rows() == 12 && C.cols() == n);
+    for (int j = 0; j < 6; ++j) {
+        int c1 = hs(j, sc.x, sc.param.camera_param, y1);
+        int c2 = hs(j, sc.x, sc.param.camera_param, y2, SR2);
+        int c3 = hs(j, sc.x, sc.param.camera_param, y3, SR3, J);
+        CHECK_TRUE(c1 == 0 && c2 == 0 && c3 == 0);
+        CHECK_TRUE(J.rows() == 2 && J.cols() == n);
+        for (int r = 0; r < 2; ++r) {
+            CHECK_NEAR(y1(r), yb1(2 * j + r), 1e-13);
+            CHECK_NEAR(y2(r), yb2(2 * j + r), 1e-13);
+            CHECK_NEAR(y3(r), yb3(2 * j + r), 1e-13);
+            CHECK_NEAR(SR3(r, r), 0.01, 1e-15);
+            CHECK_NEAR(SRb3(2 * j + r, 2 * j + r), 0.01, 1e-15);
+            for (int c = 0; c < n; ++c) CHECK_NEAR(J(r, c), C(2 * j + r, c), 1e-12);
+        }
+    }
+    // Fused device form of affineTransform(mux, Sxx, bundle, ...) against the generic one.
+    Vector muy_a, muy_b;
+    Matrix Syy_a, Syy_b;
+    affineTransform(sc.x, sc.S, hb, sc.param.camera_param, muy_a, Syy_a);
+    auto bound = [&](const Vector &xx, Vector &f, Matrix &SR, Matrix &CC) { hb(xx, sc.param.camera_param, f, SR, CC); };
+    affineTransform(sc.x, sc.S, bound, muy_b, Syy_b);
+    for (int i = 0; i < 12; ++i) {
+        CHECK_NEAR(muy_a(i), muy_b(i), 1e-12);
+        for (int j = 0; j < 12; ++j) CHECK_NEAR(Syy_a(i, j), Syy_b(i, j), 1e-9);
+    }
+}
+
+static void test_point_log_likelihood(const std::string &xml)
+{
+    Scene sc(xml, 8, 11);
+    const int n = sc.x.rows();
+    PointLogLikelihood ll;
+    Vector y, u, g2, g3;
+    Matrix H;
+    double v1 = ll(y, sc.x, u, sc.param);
+    double v2 = ll(y, sc.x, u, sc.param, g2);
+    double v3 = ll(y, sc.x, u, sc.param, g3, H);
+    CHECK_TRUE(g2.rows() == n && H.rows() == n && H.cols() == n);
+    CHECK_NEAR(v2, v1, 1e-13); CHECK_NEAR(v3, v1, 1e-13);
+    for (int i = 0; i < n; ++i) CHECK_NEAR(g3(i), g2(i), 1e-13);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) CHECK_NEAR(H(i, j), H(j, i), 1e-13);
+    for (int i = 0; i < 6; ++i) CHECK_NEAR(g2(i), 0.0, 0.0);   // the velocity states do not enter the likelihood
+    // Central differences of the value against the gradient, and of the gradient against the Hessian.
+    const double h = 1e-6;
+    for (int i = 6; i < n; i += 3) {
+        Vector xp = sc.x, xm = sc.x, gp, gm;
+        xp(i) += h; xm(i) -= h;
+        double fp = ll(y, xp, u, sc.param, gp), fm = ll(y, xm, u, sc.param, gm);
+        CHECK_NEAR((fp - fm) / (2 * h), g2(i), 1e-6);
+        for (int k = 6; k < n; k += 5) CHECK_NEAR((gp(k) - gm(k)) / (2 * h), H(k, i), 1e-5);
+    }
+}
+
+static void test_measurement_update(const std::string &xml)
+{
+    Scene sc(xml, 10, 5);
+    const int n = sc.x.rows();
+    Vector u, y, muxGy, g;
+    Matrix SxxGy;
+    int code = measurementUpdateIEKF(sc.mu, sc.S, u, y, PointLogLikelihood(), sc.param, muxGy, SxxGy);
+    CHECK_TRUE(code == 0);
+    CHECK_TRUE(muxGy.rows() == n && SxxGy.rows() == n && SxxGy.cols() == n);
+    for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) CHECK_TRUE(SxxGy(i, j) == 0.0);
+    // The posterior mean is a stationary point of -(logprior + loglik).
+    Vector gl, gp;
+    PointLogLikelihood ll;
+    ll(y, muxGy, u, sc.param, gl);
+    logGaussian(muxGy, sc.mu, sc.S, gp);
+    double gn = 0.0, scale = 0.0;
+    for (int i = 0; i < n; ++i) { gn += (gl(i) + gp(i)) * (gl(i) + gp(i)); scale += gl(i) * gl(i) + gp(i) * gp(i); }
+    CHECK_TRUE(std::sqrt(gn) <= 1e-6 * (1.0 + std::sqrt(scale)));
+    // The update does not inflate any marginal variance: diag(Spost' Spost) <= diag(S' S).
+    for (int j = 0; j < n; ++j) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i <= j; ++i) { a += SxxGy(i, j) * SxxGy(i, j); b += sc.S(i, j) * sc.S(i, j); }
+        CHECK_TRUE(a <= b * (1.0 + 1e-9));
+    }
+}
+
+static void test_condition_on_marginal()
+{
+    // Joint of [y; x] with an uncorrelated square-root factor: conditioning on y leaves x's marginal untouched.
+    Vector mu{1, 2, 3, 4}, yv{1.5, 2.5}, mc;
+    Matrix S(4, 4), Sc;
+    S(0, 0) = 2; S(1, 1) = 3; S(2, 2) = 0.5; S(3, 3) = 0.25; S(2, 3) = 0.1;
+    conditionGaussianOnMarginal(mu, S, yv, mc, Sc);
+    CHECK_TRUE(mc.rows() == 2 && Sc.rows() == 2 && Sc.cols() == 2);
+    CHECK_NEAR(mc(0), 3.0, 1e-13); CHECK_NEAR(mc(1), 4.0, 1e-13);
+    CHECK_NEAR(Sc(0, 0), 0.5, 1e-13); CHECK_NEAR(Sc(0, 1), 0.1, 1e-13); CHECK_NEAR(Sc(1, 1), 0.25, 1e-13);
+    // With correlation S12: mu_x|y = mu_x + S12' * S11^-T (y - mu_y).
+    S(0, 2) = 0.4; S(1, 3) = -0.6;
+    conditionGaussianOnMarginal(mu, S, yv, mc, Sc);
+    CHECK_NEAR(mc(0), 3.0 + 0.4 * (0.5 / 2.0), 1e-13);
+    CHECK_NEAR(mc(1), 4.0 - 0.6 * (0.5 / 3.0), 1e-13);
+}
+
+static void test_detect_corners()
+{
+    const int w = 320, h = 240;
+    std::vector<uint8_t> img((size_t)w * h, 30);
+    for (int y = 60; y < 180; ++y) for (int x = 80; x < 240; ++x) img[(size_t)y * w + x] = 220;
+    std::vector<Feature> kp;
+    detectCorners(img.data(), w, h, w, 100, 1e-4f, VSLAM_DETECTOR_HARRIS, kp);
+    CHECK_TRUE(kp.size() >= 4 && kp.size() <= 100);
+    for (size_t i = 1; i < kp.size(); ++i) CHECK_TRUE(kp[i - 1].score >= kp[i].score);
+    int near = 0;
+    const int cx[4] = {80, 239, 80, 239}, cy[4] = {60, 60, 179, 179};
+    for (int c = 0; c < 4; ++c)
+        for (const Feature &f : kp)
+            if (std::abs(f.x - cx[c]) <= 4 && std::abs(f.y - cy[c]) <= 4) { ++near; break; }
+    CHECK_TRUE(near == 4);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <camera.xml>\n", argv[0]); return 2; }
+    try {
+        test_log_gaussian();
+        test_affine_transform();
+        test_condition_on_marginal();
+        test_measurement_model(argv[1]);
+        test_point_log_likelihood(argv[1]);
+        test_measurement_update(argv[1]);
+        test_detect_corners();
+        // Contract violations surface as exceptions carrying the library's message, not aborts.
+        bool threw = false;
+        try {
+            Vector mu{1, 2, 3}, y{1, 2}, mc;
+            Matrix bad(2, 3), Sc;          // a joint factor must have at least ny + nx rows
+            conditionGaussianOnMarginal(mu, bad, y, mc, Sc);
+        }
+        catch (const std::runtime_error &) { threw = true; }
+        CHECK_TRUE(threw);
+    } catch (const std::exception &e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 99;
+    }
+    std::printf("%d checks, %d failures\n", checks, failures);
+    return failures > 98 ? 98 : failures;
+}

@@ -1,0 +1,281 @@
+// Host-side mirror of the reference's functor / free-function interface for the
+// point-landmark path, implemented over the C ABI of include/vslam_hip.h.
+//
+// Same names, argument order, output-resizing behaviour and return codes as the
+// reference (paths relative to the reference checkout):
+//   CameraParameters, importCalibrationData      src/cameraModel.hpp:12-30
+//   MeasurementPointLandmarkSingle / Bundle      src/measurementPointLandmark.hpp:9-311
+//   SlamParameters, Landmark, PointLogLikelihood src/model.hpp:12-56, src/imagefeatures.h:21-27
+//   logGaussian, affineTransform,
+//   measurementUpdateIEKF                         src/gaussian.hpp:30-131,469-532
+//   conditionGaussianOnMarginal                   src/gaussian.cpp:19-36
+//   Feature, detectCorners                        src/imagefeatures.h:15-19,37
+// The reference passes Eigen objects; Eigen is not a dependency here, so the
+// mirror uses two tiny column-major value types (Vector, Matrix) with the same
+// resize / data / rows / cols surface.  With Eigen available the functors accept
+// Eigen::VectorXd / MatrixXd unchanged: only .data(),
+// .rows(), .cols(), .size() and .resize() are used.
+//
+// Contract violations that the reference asserts on throw std::runtime_error
+// carrying the library's message.
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <initializer_list>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam_hip.h"
+
+namespace vslam_host {
+
+struct Vector {
+    std::vector<double> v;
+    Vector() = default;
+    explicit Vector(int n) : v((size_t)n, 0.0) {}
+    Vector(std::initializer_list<double> l) : v(l) {}
+    int rows() const { return (int)v.size(); }
+    int cols() const { return 1; }
+    int size() const { return (int)v.size(); }
+    void resize(int n, int = 1) { v.resize((size_t)n); }
+    double *data() { return v.data(); }
+    const double *data() const { return v.data(); }
+    double &operator()(int i) { return v[(size_t)i]; }
+    double operator()(int i) const { return v[(size_t)i]; }
+};
+
+struct Matrix {                       // column-major, leading dimension == rows
+    std::vector<double> v;
+    int r = 0, c = 0;
+    Matrix() = default;
+    Matrix(int rows, int cols) : v((size_t)rows * cols, 0.0), r(rows), c(cols) {}
+    int rows() const { return r; }
+    int cols() const { return c; }
+    int size() const { return r * c; }
+    void resize(int rows, int cols) { r = rows; c = cols; v.assign((size_t)rows * cols, 0.0); }
+    double *data() { return v.data(); }
+    const double *data() const { return v.data(); }
+    double &operator()(int i, int j) { return v[(size_t)j * r + i]; }
+    double operator()(int i, int j) const { return v[(size_t)j * r + i]; }
+};
+
+// One process-wide device context (device 0 unless VSLAM_DEVICE says otherwise).
+inline vslam_ctx *context()
+{
+    static vslam_ctx *ctx = [] {
+        vslam_ctx *c = nullptr;
+        int dev = 0;
+        if (const char *e = std::getenv("VSLAM_DEVICE")) dev = std::atoi(e);
+        vslam_status s = vslam_ctx_create(dev, &c);
+        if (s != VSLAM_OK) throw std::runtime_error(std::string("vslam: cannot create a context: ") + vslam_status_string(s));
+        return c;
+    }();
+    return ctx;
+}
+
+inline void check(vslam_status s)
+{
+    if (s != VSLAM_OK)
+        throw std::runtime_error(std::string("vslam: ") + vslam_status_string(s) + ": " + vslam_last_error(context()));
+}
+
+// ---- camera -------------------------------------------------------------
+struct CameraParameters {
+    vslam_camera cam{};
+    CameraParameters() { cam.fov_deg = 120.0; }
+};
+inline void importCalibrationData(const std::string &calibrationFilePath, CameraParameters &param)
+{
+    vslam_status s = vslam_camera_from_xml(calibrationFilePath.c_str(), &param.cam);
+    if (s != VSLAM_OK) throw std::runtime_error("vslam: cannot read " + calibrationFilePath);
+}
+
+// ---- measurement model ----------------------------------------------------
+// layout: VSLAM_LAYOUT_COMPAT reproduces the reference's Jacobian column placement.
+struct MeasurementPointLandmarkSingle {
+    int layout = VSLAM_LAYOUT_COMPAT;
+    template <class Vec> int operator()(const int &j, const Vec &x, const CameraParameters &param, Vec &rQOi) const
+    {
+        int32_t code = 0;
+        rQOi.resize(2, 1);
+        check(vslam_single_measure(context(), &param.cam, j, x.data(), (int)x.rows(), layout, rQOi.data(), nullptr, nullptr, &code));
+        return code;
+    }
+    template <class Vec, class Mat> int operator()(const int &j, const Vec &x, const CameraParameters &param, Vec &rQOi, Mat &SR) const
+    {
+        int32_t code = 0;
+        rQOi.resize(2, 1); SR.resize(2, 2);
+        check(vslam_single_measure(context(), &param.cam, j, x.data(), (int)x.rows(), layout, rQOi.data(), SR.data(), nullptr, &code));
+        return code;
+    }
+    template <class Vec, class Mat> int operator()(const int &j, const Vec &x, const CameraParameters &param, Vec &rQOi, Mat &SR, Mat &J) const
+    {
+        int32_t code = 0;
+        rQOi.resize(2, 1); SR.resize(2, 2); J.resize(2, (int)x.rows());
+        check(vslam_single_measure(context(), &param.cam, j, x.data(), (int)x.rows(), layout, rQOi.data(), SR.data(), J.data(), &code));
+        return code;
+    }
+};
+
+struct MeasurementPointLandmarkBundle {
+    int layout = VSLAM_LAYOUT_COMPAT;
+    template <class Vec> void operator()(const Vec &x, const CameraParameters &param, Vec &rQOi) const
+    {
+        const int L = ((int)x.rows() - 12) / 3;
+        rQOi.resize(2 * L, 1);
+        check(vslam_bundle_measure(context(), &param.cam, x.data(), (int)x.rows(), layout, rQOi.data(), nullptr, nullptr, nullptr));
+    }
+    template <class Vec, class Mat> void operator()(const Vec &x, const CameraParameters &param, Vec &rQOi, Mat &SR) const
+    {
+        const int L = ((int)x.rows() - 12) / 3;
+        rQOi.resize(2 * L, 1); SR.resize(2 * L, 2 * L);
+        check(vslam_bundle_measure(context(), &param.cam, x.data(), (int)x.rows(), layout, rQOi.data(), SR.data(), nullptr, nullptr));
+    }
+    template <class Vec, class Mat> void operator()(const Vec &x, const CameraParameters &param, Vec &rQOi, Mat &SR, Mat &C) const
+    {
+        const int L = ((int)x.rows() - 12) / 3;
+        rQOi.resize(2 * L, 1); SR.resize(2 * L, 2 * L); C.resize(2 * L, (int)x.rows());
+        check(vslam_bundle_measure(context(), &param.cam, x.data(), (int)x.rows(), layout, rQOi.data(), SR.data(), C.data(), nullptr));
+    }
+};
+
+// ---- log-likelihood ---------------------------------------------------------
+struct Landmark {                      // the fields of the reference's Landmark that the likelihood reads
+    bool isVisible = false;
+    double pixel_measurement[2] = {0.0, 0.0};
+};
+struct SlamParameters {
+    CameraParameters camera_param;
+    double measurement_noise = 7.0;
+    std::vector<Landmark> landmarks;
+};
+
+namespace detail {
+inline void pack(const SlamParameters &p, std::vector<double> &y, std::vector<uint8_t> &vis)
+{
+    y.resize(2 * p.landmarks.size());
+    vis.resize(p.landmarks.size());
+    for (size_t j = 0; j < p.landmarks.size(); ++j) {
+        y[2 * j] = p.landmarks[j].pixel_measurement[0];
+        y[2 * j + 1] = p.landmarks[j].pixel_measurement[1];
+        vis[j] = p.landmarks[j].isVisible ? 1 : 0;
+    }
+}
+}  // namespace detail
+
+struct PointLogLikelihood {
+    // y and u are ignored, as in the reference (measurements travel in param.landmarks).
+    template <class Vec> double operator()(const Vec &, const Vec &x, const Vec &, const SlamParameters &param) const
+    {
+        std::vector<double> y; std::vector<uint8_t> vis; detail::pack(param, y, vis);
+        double val = 0.0;
+        check(vslam_point_loglik(context(), &param.camera_param.cam, x.data(), (int)x.rows(), y.data(), vis.data(),
+                                 param.measurement_noise, &val, nullptr, nullptr, 0, nullptr));
+        return val;
+    }
+    template <class Vec> double operator()(const Vec &, const Vec &x, const Vec &, const SlamParameters &param, Vec &g) const
+    {
+        std::vector<double> y; std::vector<uint8_t> vis; detail::pack(param, y, vis);
+        double val = 0.0;
+        g.resize((int)x.rows(), 1);
+        check(vslam_point_loglik(context(), &param.camera_param.cam, x.data(), (int)x.rows(), y.data(), vis.data(),
+                                 param.measurement_noise, &val, g.data(), nullptr, 0, nullptr));
+        return val;
+    }
+    template <class Vec, class Mat> double operator()(const Vec &, const Vec &x, const Vec &, const SlamParameters &param, Vec &g, Mat &H) const
+    {
+        std::vector<double> y; std::vector<uint8_t> vis; detail::pack(param, y, vis);
+        double val = 0.0;
+        const int n = (int)x.rows();
+        g.resize(n, 1); H.resize(n, n);
+        check(vslam_point_loglik(context(), &param.camera_param.cam, x.data(), n, y.data(), vis.data(),
+                                 param.measurement_noise, &val, g.data(), H.data(), n, nullptr));
+        return val;
+    }
+};
+
+// ---- Gaussian algebra ---------------------------------------------------------
+template <class Vec, class Mat> double logGaussian(const Vec &x, const Vec &mu, const Mat &S)
+{
+    double v = 0.0;
+    check(vslam_log_gaussian(context(), x.data(), mu.data(), S.data(), (int)x.rows(), (int)S.rows(), &v, nullptr, nullptr));
+    return v;
+}
+template <class Vec, class Mat> double logGaussian(const Vec &x, const Vec &mu, const Mat &S, Vec &g)
+{
+    double v = 0.0;
+    g.resize((int)x.rows(), 1);
+    check(vslam_log_gaussian(context(), x.data(), mu.data(), S.data(), (int)x.rows(), (int)S.rows(), &v, g.data(), nullptr));
+    return v;
+}
+template <class Vec, class Mat> double logGaussian(const Vec &x, const Vec &mu, const Mat &S, Vec &g, Mat &H)
+{
+    double v = 0.0;
+    g.resize((int)x.rows(), 1); H.resize((int)x.rows(), (int)x.rows());
+    check(vslam_log_gaussian(context(), x.data(), mu.data(), S.data(), (int)x.rows(), (int)S.rows(), &v, g.data(), H.data()));
+    return v;
+}
+
+// affineTransform(mux, Sxx, h, muy, Syy): h is any functor h(x, y, SR, C) (src/gaussian.hpp:85-131).
+template <class Func, class Vec, class Mat> void affineTransform(const Vec &mux, const Mat &Sxx, Func h, Vec &muy, Mat &Syy)
+{
+    if (mux.size() <= 0 || Sxx.cols() != Sxx.rows() || mux.rows() != Sxx.rows()) throw std::runtime_error("affineTransform: bad input shapes");
+    Mat SR, C;
+    h(mux, muy, SR, C);
+    const int m = (int)muy.size(), n = (int)mux.size();
+    if (m <= 0 || SR.rows() != m || SR.cols() != m || C.rows() != m || C.cols() != n) throw std::runtime_error("affineTransform: bad model output shapes");
+    Syy.resize(m, m);
+    check(vslam_affine_sqrt(context(), Sxx.data(), n, (int)Sxx.rows(), C.data(), m, (int)C.rows(), SR.data(), (int)SR.rows(), Syy.data(), m));
+}
+// The call of src/SLAM.cpp:371-387 (h = MeasurementPointLandmarkBundle bound to the camera), fused on the device.
+template <class Vec, class Mat>
+void affineTransform(const Vec &mux, const Mat &Sxx, const MeasurementPointLandmarkBundle &h, const CameraParameters &param, Vec &muy, Mat &Syy)
+{
+    const int n = (int)mux.size(), m = 2 * ((n - 12) / 3);
+    muy.resize(m, 1); Syy.resize(m, m);
+    check(vslam_affine_bundle(context(), &param.cam, mux.data(), Sxx.data(), n, (int)Sxx.rows(), h.layout, muy.data(), Syy.data(), m, nullptr));
+}
+
+template <class Vec, class Mat>
+void conditionGaussianOnMarginal(const Vec &muyxjoint, const Mat &Syxjoint, const Vec &y, Vec &muxcond, Mat &Sxcond)
+{
+    const int ny = (int)y.rows(), nx = (int)Syxjoint.cols() - ny;
+    muxcond.resize(nx, 1); Sxcond.resize(nx, nx);
+    check(vslam_condition_on_marginal(context(), muyxjoint.data(), Syxjoint.data(), ny, nx, (int)Syxjoint.rows(), y.data(),
+                                      muxcond.data(), Sxcond.data(), nx));
+}
+
+// measurementUpdateIEKF(mux, Sxx, u, y, PointLogLikelihood, param, muxGy, SxxGy), src/gaussian.hpp:469-532
+// as called at src/SLAM.cpp:492.  Returns fmin's code (0 converged, 1 iteration limit).
+template <class Vec, class Mat>
+int measurementUpdateIEKF(const Vec &mux, const Mat &Sxx, const Vec &, const Vec &, PointLogLikelihood, const SlamParameters &param,
+                          Vec &muxGy, Mat &SxxGy)
+{
+    std::vector<double> y; std::vector<uint8_t> vis; detail::pack(param, y, vis);
+    const int n = (int)mux.size();
+    muxGy.resize(n, 1); SxxGy.resize(n, n);
+    int32_t code = 0;
+    check(vslam_measurement_update_iekf(context(), &param.camera_param.cam, mux.data(), Sxx.data(), n, (int)Sxx.rows(), y.data(), vis.data(),
+                                        param.measurement_noise, muxGy.data(), SxxGy.data(), n, &code, nullptr, nullptr));
+    return code;
+}
+
+// ---- corner front end ---------------------------------------------------------
+using Feature = vslam_feature;         // {int x; int y; float score;}, src/imagefeatures.h:15-19
+// Keypoints of one 8-bit grayscale frame sorted by score (sortByScore, src/imagefeatures.cpp:20-22).
+inline int detectCorners(const uint8_t *gray, int width, int height, int stride, int maxNumFeatures, float threshold,
+                         int detector, std::vector<Feature> &keypoints)
+{
+    vslam_corner_params p{};
+    p.block_size = 7; p.border = 5; p.max_features = maxNumFeatures; p.harris_k = 0.04f;
+    p.harris_thresh = threshold; p.shi_thresh = threshold;
+    keypoints.resize((size_t)maxNumFeatures);
+    int32_t count = 0;
+    check(vslam_corner_detect(context(), gray, width, height, stride, &p, detector, keypoints.data(), maxNumFeatures, &count));
+    keypoints.resize((size_t)count);
+    return 0;
+}
+
+}  // namespace vslam_host
