@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Times one full measurementUpdateIEKF (host-pointer entry point) at L landmarks: python tools/run_iekf.py [L] [reps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visualslam_amd import api, synthetic as syn  # noqa: E402
+
+
+def main():
+    L = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    sc = syn.Scene(L, 42, dense_S=True)
+    ctx = api.Context(0)
+    cam = api.camera_from_xml(syn.CAMERA_XML)
+    rng = np.random.default_rng(5)
+    mu = sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)])
+    out = api.measurement_update_iekf(ctx, cam, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = api.measurement_update_iekf(ctx, cam, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    dt = (time.perf_counter() - t0) / reps
+    print("L=%d n=%d: measurement_update_iekf %.2f ms  (code %d, iterations %d, cost evaluations %d)" % (L, sc.n, dt * 1e3, out[0], out[3], out[4]), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,10 @@ struct vslam_ctx {
     size_t scratch_bytes = 0;    // entry point's carve-up of `ws` stays valid across launches
     void *pinned = nullptr;      // small pinned host staging buffer
     size_t pinned_bytes = 0;
+    hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose barrier gave up
+    int *flags_host = nullptr;   // pinned mirror read by stream_finish
     char err[512] = {0};
 };
 
@@ -55,6 +59,10 @@ inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
 // across a growth.  Synchronises the stream before freeing the old block.
 vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes);
 vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes);
+// Synchronises the context's stream and turns a raised device flag into an error.
+vslam_status stream_finish(vslam_ctx *ctx);
+// Creates ctx->side and ctx->ev[] on first use.
+vslam_status side_stream_init(vslam_ctx *ctx);
 
 // Carves 256-byte aligned sub-buffers out of the workspace.
 struct Arena {

@@ -44,6 +44,27 @@ vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes)
     return VSLAM_OK;
 }
 
+vslam_status side_stream_init(vslam_ctx *ctx)
+{
+    if (ctx->side) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i) VSLAM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+    return VSLAM_OK;
+}
+
+vslam_status stream_finish(vslam_ctx *ctx)
+{
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->flags_host, ctx->flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->flags_host[0] != 0) {
+        ctx->flags_host[0] = 0;
+        VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->flags, 0, sizeof(int), ctx->stream));
+        return fail(ctx, VSLAM_ERR_DEVICE, "a multi-workgroup kernel gave up waiting at its barrier; results are invalid");
+    }
+    return VSLAM_OK;
+}
+
 vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *k)
 {
     const int RATIONAL = 0x4000, THIN = 0x8000;
@@ -117,6 +138,13 @@ static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VSLAM_ERR_DEVICE; }
         c->own_stream = true;
     }
+    if (hipMalloc(reinterpret_cast<void **>(&c->flags), 64 * sizeof(int)) != hipSuccess ||
+        hipMemset(c->flags, 0, 64 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        vslam_ctx_destroy(c);
+        return VSLAM_ERR_ALLOC;
+    }
+    c->flags_host[0] = 0;
     *out = c;
     return VSLAM_OK;
 }
@@ -135,6 +163,10 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VSLAM_OK;
@@ -143,8 +175,7 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
 vslam_status vslam_ctx_synchronize(vslam_ctx *ctx)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 // Reads the numbers of <tag> ... <data> n n n </data> ... </tag>.

@@ -217,8 +217,7 @@ extern "C" vslam_status vslam_log_gaussian(vslam_ctx *ctx, const double *x, cons
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(value, dval, 8, hipMemcpyDeviceToHost, s));
     if (g) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g, dg, n * 8, hipMemcpyDeviceToHost, s));
     if (H) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H, dH, nn * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 extern "C" vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n, int ldS, const double *C, int m, int ldC,
@@ -244,8 +243,7 @@ extern "C" vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n
     VSLAM_TRY(gemm_f64(ctx, d));
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, 0, 1, qws));
     VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *cam, const double *mux, const double *Sxx,
@@ -279,8 +277,7 @@ extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(muy, dh, m * 8, hipMemcpyDeviceToHost, s));
     if (code) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, L * 4, hipMemcpyDeviceToHost, s));
     VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out)
@@ -301,8 +298,7 @@ extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, co
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     VSLAM_TRY(qr_upper_dev(ctx, dA, n, n, n, 0, 1, qws));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(S_out, dA, nn * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 extern "C" vslam_status vslam_condition_on_marginal(vslam_ctx *ctx, const double *muyx, const double *Syx, int ny, int nx, int ld,
@@ -328,8 +324,7 @@ extern "C" vslam_status vslam_condition_on_marginal(vslam_ctx *ctx, const double
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mux_out, dout, nx * 8, hipMemcpyDeviceToHost, s));
     VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Sx_out, (size_t)ldo * 8, dSx, (size_t)nx * 8, (size_t)nx * 8, nx, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 // ---- cost state shared with the IEKF driver (iekf.cpp) ----
@@ -406,6 +401,5 @@ extern "C" vslam_status vslam_cost_joint_density(vslam_ctx *ctx, const vslam_cam
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(value, c.vals + 2, 8, hipMemcpyDeviceToHost, s));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g, c.g, n * 8, hipMemcpyDeviceToHost, s));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H, c.H, nn * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }

@@ -158,7 +158,9 @@ static void launch(const GemmArgs &a, dim3 grid, hipStream_t s, bool ta, bool tb
     else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, a);
 }
 
-vslam_status gemm_f64(vslam_ctx *ctx, const GemmDesc &d)
+vslam_status gemm_f64(vslam_ctx *ctx, const GemmDesc &d) { return gemm_f64_on(ctx, d, ctx->stream); }
+
+vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream)
 {
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return VSLAM_OK;
     if (!d.A || !d.B || !d.C) return fail(ctx, VSLAM_ERR_ARG, "gemm: null operand");
@@ -176,8 +178,8 @@ vslam_status gemm_f64(vslam_ctx *ctx, const GemmDesc &d)
     a.tilesM = (d.M + bm - 1) / bm;
     const int tilesN = (d.N + bn - 1) / bn;
     dim3 grid(a.tilesM * tilesN, d.ksplit, d.batch);
-    if (smallM) launch<32, 64>(a, grid, ctx->stream, d.transA, d.transB);
-    else launch<64, 64>(a, grid, ctx->stream, d.transA, d.transB);
+    if (smallM) launch<32, 64>(a, grid, stream, d.transA, d.transB);
+    else launch<64, 64>(a, grid, stream, d.transA, d.transB);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }

@@ -32,6 +32,7 @@ struct GemmDesc {
 
 // C = alpha * op(A) * op(B) + beta * C on v_mfma_f64_16x16x4_f64.
 vslam_status gemm_f64(vslam_ctx *ctx, const GemmDesc &d);
+vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream);   // same, on an explicit stream
 
 // In-place Householder QR of `batch` matrices (rows x cols, leading dimension
 // lda, element stride strideA); on return the upper triangle holds R (LAPACK /

@@ -20,6 +20,7 @@
 // V is read straight out of the factored panel (unit diagonal and zeros above
 // it are synthesised by the GEMM's operand loader).
 #include "linalg.hpp"
+#include <cstdlib>
 
 namespace vslam {
 
@@ -54,10 +55,10 @@ __device__ __forceinline__ void block_reduce_nb(double (&acc)[NB + 1], int count
 }
 
 __global__ __launch_bounds__(PT) void qr_panel_kernel(double *Abase, int lda, size_t strideA, int mp, int jb,
-                                                      double *Tbase /*[batch][NB*NB]*/)
+                                                      double *Tbase /*[batch][NB*NB + NB], T column-major ld NB*/)
 {
     double *A = Abase + (size_t)blockIdx.x * strideA;       // panel origin (row j0, column j0)
-    double *Tg = Tbase + (size_t)blockIdx.x * NB * NB;
+    double *Tg = Tbase + (size_t)blockIdx.x * (NB * NB + NB);
     __shared__ double T[NB][NB + 1];
     __shared__ double red[(PT / 64) * (NB + 1)];
     __shared__ double z[NB + 1], y[NB], u[NB + 1];
@@ -150,37 +151,342 @@ __global__ __launch_bounds__(PT) void qr_panel_kernel(double *Abase, int lda, si
     for (int i = tid; i < NB * NB; i += PT) Tg[i] = T[i % NB][i / NB];   // column-major, ld NB
 }
 
-// W2[0:jb, n] = T^T * sum_s Wpart[s][0:jb, n]
-__global__ __launch_bounds__(256) void qr_apply_t_kernel(const double *Tbase, const double *Wpart, size_t strideSplit,
-                                                         size_t strideBatchW, int ksplit, int jb, int n2, int ldw,
-                                                         double *W2, size_t strideBatchW2)
+// ---- tall panels: many workgroups per panel --------------------------------------
+// A panel of several thousand rows keeps one workgroup busy for milliseconds, so a
+// single large matrix is factored by G co-resident workgroups per panel instead.
+// Workgroup g holds rows [g*rows_per, (g+1)*rows_per) of the m x 32 panel in LDS for
+// the whole factorisation (right-looking, column by column, the order of LAPACK's
+// dgeqr2).  Column c needs ONE exchange: every workgroup publishes
+//     p_k = sum_{i > c, i in its rows} P[i][k] * P[i][c],   k = 0..31
+// (k = c: squared norm of the tail; k > c: tail dot products for the update;
+//  k < c: V_k^T x_c for the compact-WY T) and, if it owns row c, that row; every
+// workgroup then adds the G partial vectors in the same order, so all of them derive
+// bit-identical beta / tau / w and update their own rows.  One LDS pass applies
+// reflector c and accumulates the dot products of column c+1.
+//
+// The exchange has no counter: a slot holds a reserved NaN bit pattern until its data
+// arrives, and readers poll the data words themselves (one round trip).  Slots rotate
+// through three buffers indexed by a column count that keeps running across the panel
+// launches of one factorisation: publishing column t first marks the slot of t+1 empty
+// (nobody reads that buffer any more: t-2 was consumed before anyone published t-1),
+// then release-stores the data of t.  A genuine input NaN with the reserved payload
+// would stall the poll; it ends at the iteration bound, raises *err, and every wave
+// still runs to the end.  The launcher keeps G * batch <= 240 so all workgroups are
+// resident together.
+#ifndef VSLAM_CP_T
+#define VSLAM_CP_T 1024
+#endif
+constexpr int CP_T = VSLAM_CP_T;     // threads per workgroup
+constexpr int CP_NG = CP_T / 32;     // row groups (each 32 lanes = the panel's 32 columns)
+constexpr int CP_RMAX = 512;         // most rows a workgroup holds
+constexpr int CP_LD = NB + 1;        // LDS row stride (doubles)
+constexpr int CP_GMAX = 64;          // most workgroups per panel (8 polled slots per thread)
+constexpr int CP_SLOT = 2 * NB;      // doubles per slot: partial sums, then row c
+constexpr unsigned CP_EMPTY32 = 0x7FF8DEADu;
+constexpr unsigned long long CP_EMPTY = 0x7FF8DEAD7FF8DEADull;
+constexpr unsigned CP_SPIN_LIMIT = 1u << 22;
+constexpr int MSTRIDE = NB * NB + NB;   // doubles reserved per panel for T (column-major, ld NB)
+
+struct CoopPanelArgs {
+    double *A;            // panel origin (row j0, column j0) of matrix 0
+    int lda;
+    size_t strideA;
+    int mp, jb, rows_per, G;
+    unsigned tbase;       // running column count at the first column of this launch
+    double *M;            // [batch][MSTRIDE]: the panel's compact-WY T, column-major ld NB
+    double *slots;        // [batch][3][CP_GMAX][CP_SLOT]
+    int *err;
+    double *V;            // optional: explicit reflectors (unit diagonal, zeros above), element (panel row 0, panel column 0)
+    int ldv, vzero;       // leading dimension; rows above the panel to clear in these columns
+};
+
+__device__ __forceinline__ size_t coop_lds_doubles(int rows_per)
 {
-    __shared__ double T[NB * NB];
-    const int b = blockIdx.y;
-    const double *Tg = Tbase + (size_t)b * NB * NB;
-    for (int i = threadIdx.x; i < NB * NB; i += 256) T[i] = Tg[i];
-    __syncthreads();
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= n2) return;
-    double w[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) w[k] = 0.0;
-    for (int s = 0; s < ksplit; ++s) {
-        const double *src = Wpart + (size_t)b * strideBatchW + (size_t)s * strideSplit + (size_t)n * ldw;
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (k < jb) w[k] += src[k];
+    return (size_t)rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4;
+}
+
+__device__ __forceinline__ double coop_poll(const double *p, int *err, bool &dead)
+{
+    unsigned spins = 0;
+    for (;;) {
+        const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__double_as_longlong(v) != (long long)CP_EMPTY || dead) return v;
+        if ((++spins & 255u) == 0) {
+            if (spins > CP_SPIN_LIMIT) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; return 0.0; }
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
-    double *dst = W2 + (size_t)b * strideBatchW2 + (size_t)n * ldw;
+}
+
+__global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
+{
+    extern __shared__ double lds[];
+    double *P = lds;                                   // [rows_per][CP_LD]
+    double *red = P + (size_t)a.rows_per * CP_LD;      // [CP_NG][NB]
+    double *tot = red + CP_NG * NB;                        // [NB]
+    double *rc = tot + NB;                             // [NB] row c of the panel
+    double *w = rc + NB;                               // [NB]
+    double *Ms = w + NB;                               // [NB][NB+1]: Ms[k][r] = v_k^T v_r, k < r; row NB-ish tail: taus
+    double *sc = Ms + NB * (NB + 1);                   // tau, scale, beta
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int k = tid & (NB - 1), grp = tid >> 5;      // CP_NG row groups x 32 columns
+    double *A = a.A + (size_t)b * a.strideA;
+    double *slots = a.slots + (size_t)b * 3 * CP_GMAX * CP_SLOT;
+    const int r0 = g * a.rows_per;
+    const int nr = min(a.rows_per, a.mp - r0);         // >= 1 by construction of G
+    const int jb = a.jb, G = a.G;
+    bool dead = false;
+
+    for (int idx = tid; idx < nr * NB; idx += CP_T) {
+        const int li = idx % nr, kk = idx / nr;
+        P[li * CP_LD + kk] = (kk < jb) ? A[(size_t)kk * a.lda + r0 + li] : 0.0;
+    }
+    for (int i = tid; i < NB * (NB + 1); i += CP_T) Ms[i] = 0.0;
+    __syncthreads();
+
+    // red[grp][k] holds this workgroup's partial sums for column `col`; publish them (and row `col`).
+    // Thread k < 32 owns words k and 32+k of the slot: it empties both in the next buffer
+    // before its release-store of partial word k, the word every reader waits for.
+    auto publish = [&](int col) {
+        if (tid < NB) {
+            const unsigned t = a.tbase + (unsigned)col;
+            double *next = slots + ((size_t)((t + 1) % 3) * CP_GMAX + g) * CP_SLOT;
+            double *cur = slots + ((size_t)(t % 3) * CP_GMAX + g) * CP_SLOT;
+            const double empty = __longlong_as_double((long long)CP_EMPTY);
+            __hip_atomic_store(&next[tid], empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&next[NB + tid], empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (col >= r0 && col < r0 + nr)
+                __hip_atomic_store(&cur[NB + tid], P[(col - r0) * CP_LD + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
-        if (k < jb) {
+            for (int q = 0; q < CP_NG / 2; ++q) v += red[q * NB + tid];
+            __hip_atomic_store(&cur[tid], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // dot products of the tail of column 0 with every column
+    {
+        double s = 0.0;
+        const int lo = max(1 - r0, 0);
+        for (int li = lo + grp; li < nr; li += CP_NG) s += P[li * CP_LD + k] * P[li * CP_LD];
+        s += __shfl_xor(s, 32, 64);
+            if ((tid & 32) == 0) red[(tid >> 6) * NB + k] = s;
+    }
+    __syncthreads();
+    publish(0);
+
+    for (int c = 0; c < jb; ++c) {
+        const unsigned t = a.tbase + (unsigned)c;
+        const double *cur = slots + (size_t)(t % 3) * CP_GMAX * CP_SLOT;
+        // every workgroup adds the partials in the same order
+        {
+            double v[(CP_GMAX + CP_NG - 1) / CP_NG];
+#pragma unroll
+            for (int j = 0; j < (CP_GMAX + CP_NG - 1) / CP_NG; ++j) {
+                const int q = grp + CP_NG * j;
+                v[j] = (q < G) ? __hip_atomic_load(&cur[(size_t)q * CP_SLOT + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
             double s = 0.0;
 #pragma unroll
-            for (int l = 0; l < NB; ++l)
-                if (l <= k) s += T[l + k * NB] * w[l];       // (T^T)[k][l] = T[l][k]
-            dst[k] = s;
+            for (int j = 0; j < (CP_GMAX + CP_NG - 1) / CP_NG; ++j) {
+                const int q = grp + CP_NG * j;
+                if (q < G && __double_as_longlong(v[j]) == (long long)CP_EMPTY) v[j] = coop_poll(&cur[(size_t)q * CP_SLOT + k], a.err, dead);
+                s += v[j];
+            }
+            __syncthreads();                           // red is free: publish() of this column has read it
+            s += __shfl_xor(s, 32, 64);
+            if ((tid & 32) == 0) red[(tid >> 6) * NB + k] = s;
+            if (tid < NB) rc[tid] = coop_poll(&cur[(size_t)(c / a.rows_per) * CP_SLOT + NB + tid], a.err, dead);
         }
+        __syncthreads();
+        if (tid < NB) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < CP_NG / 2; ++q) s += red[q * NB + tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double alpha = rc[c], tail = tot[c];
+            double beta, tau, scale;
+            if (tail <= 2.2250738585072014e-308) { beta = alpha; tau = 0.0; scale = 0.0; }
+            else {
+                beta = sqrt(alpha * alpha + tail);
+                if (alpha >= 0.0) beta = -beta;
+                scale = 1.0 / (alpha - beta);
+                tau = (beta - alpha) / beta;
+            }
+            sc[0] = tau; sc[1] = scale; sc[2] = beta;
+        }
+        __syncthreads();
+        const double tau = sc[0], scale = sc[1], beta = sc[2];
+        // (V^T v_c)_k for k < c goes to the inverse-T form; w_k = tau * v_c^T a_k for k > c
+        if (tid < NB) {
+            const double vta = rc[tid] + scale * tot[tid];
+            if (tid < c) Ms[tid * (NB + 1) + c] = vta;
+            if (tid == c) Ms[c * (NB + 1) + NB] = tau;      // taus live in the pad column
+            w[tid] = (tid > c && tid < jb) ? tau * vta : 0.0;
+        }
+        __syncthreads();
+        // one pass over this workgroup's rows >= c: apply reflector c, accumulate the
+        // dot products of the tail (rows > c+1) of the updated column c+1 with every column
+        double s = 0.0;
+        {
+            const double wk = w[k];
+            const int c1 = (c + 1 < NB) ? c + 1 : c;   // column whose dots are accumulated (unused when c+1 == jb)
+            const double wc1 = w[c1];
+            const int lo = max(c - r0, 0);
+            for (int li0 = lo + grp; li0 < nr; li0 += 4 * CP_NG) {
+                double xc[4], x1[4], xk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double *row = P + min(li0 + CP_NG * u, nr - 1) * CP_LD;
+                    xc[u] = row[c]; x1[u] = row[c1]; xk[u] = row[k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int li = li0 + CP_NG * u, i = r0 + li;
+                    if (li < nr) {
+                        const double vi = (i == c) ? 1.0 : xc[u] * scale;
+                        const double nk = (k > c) ? xk[u] - vi * wk : ((k == c) ? ((i == c) ? beta : vi) : xk[u]);
+                        const double n1 = x1[u] - vi * wc1;
+                        if (k >= c) P[li * CP_LD + k] = nk;
+                        if (i > c + 1) s += nk * n1;
+                    }
+                }
+            }
+        }
+        __syncthreads();                               // T / red readers of this column are done; rows are updated
+        if (c + 1 < jb) {
+            s += __shfl_xor(s, 32, 64);
+            if ((tid & 32) == 0) red[(tid >> 6) * NB + k] = s;
+            __syncthreads();
+            publish(c + 1);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nr * jb; idx += CP_T) {
+        const int li = idx % nr, kk = idx / nr;
+        A[(size_t)kk * a.lda + r0 + li] = P[li * CP_LD + kk];
+    }
+    if (a.V) {
+        for (int idx = tid; idx < nr * jb; idx += CP_T) {
+            const int li = idx % nr, kk = idx / nr, i = r0 + li;
+            a.V[(size_t)kk * a.ldv + i] = (i < kk) ? 0.0 : ((i == kk) ? 1.0 : P[li * CP_LD + kk]);
+        }
+        if (g == 0)
+            for (int idx = tid; idx < a.vzero * jb; idx += CP_T) {
+                const int z = idx % a.vzero, kk = idx / a.vzero;
+                a.V[(ptrdiff_t)kk * a.ldv - 1 - z] = 0.0;
+            }
+    }
+    // T = (striu(V^T V) + diag(1/tau))^-1: lane j back-substitutes column j (a reflector with
+    // tau = 0 gives a zero row and column).
+    if (g == 0 && tid < NB) {
+        double *Mg = a.M + (size_t)b * MSTRIDE;
+        const int j = tid;
+        double t[NB];
+#pragma unroll
+        for (int i = NB - 1; i >= 0; --i) {
+            const double tau_i = Ms[i * (NB + 1) + NB];
+            double sum = 0.0;
+#pragma unroll
+            for (int l = i + 1; l < NB; ++l) sum += Ms[i * (NB + 1) + l] * t[l];
+            t[i] = (i == j) ? tau_i : ((i < j) ? -tau_i * sum : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Mg[j * NB + i] = t[i];
+    }
+}
+
+// W = T^T Y for a block of `ob` <= 128 reflectors made of panels of 32 whose own T_p are known
+// (Tsm[p], column-major ld NB): the block T is never formed; with G = V^T V,
+//   w_p = T_p^T ( y_p - G[p-rows, earlier rows] w_{<p} ),  p = 0, 1, ...
+// Y arrives as `ks` K-slabs that are summed on load.  A workgroup owns 16 columns; lane r of a
+// 32-lane group owns row 32p + r of one column.
+constexpr int SOLVE_CT = 16;
+__global__ __launch_bounds__(256) void qr_block_solve_kernel(const double *Ypart, size_t strideSplit, int ks, int ldy,
+                                                             size_t strideBatchY, int ob, int n2, const double *Gbig,
+                                                             const double *Tsm, size_t strideBatchT, double *Wout, int ldw,
+                                                             size_t strideBatchW)
+{
+    constexpr int OBM = 128;
+    __shared__ double Ys[OBM][SOLVE_CT + 1];
+    __shared__ double Gp[OBM][NB + 1];
+    const int tid = threadIdx.x, r = tid & 31, cg = tid >> 5, b = blockIdx.y;
+    const int c0 = blockIdx.x * SOLVE_CT;
+    const double *Y = Ypart + (size_t)b * strideBatchY;
+    const double *Tb = Tsm + (size_t)b * strideBatchT;
+    double *W = Wout + (size_t)b * strideBatchW;
+    for (int idx = tid; idx < ob * SOLVE_CT; idx += 256) {
+        const int row = idx % ob, c = idx / ob, col = c0 + c;
+        double v = 0.0;
+        if (col < n2)
+            for (int sidx = 0; sidx < ks; ++sidx) v += Y[(size_t)sidx * strideSplit + (size_t)col * ldy + row];
+        Ys[row][c] = v;
+    }
+    const int np = (ob + NB - 1) / NB;
+    for (int p = 0; p < np; ++p) {
+        const int h = p * NB, wq = min(NB, ob - h);
+        const double *Tp = Tb + (size_t)p * MSTRIDE;
+        __syncthreads();
+        for (int idx = tid; idx < h * NB; idx += 256) {              // Gp[l][r] = G(h + r, l), l < h
+            const int l = idx / NB, rr = idx % NB;
+            Gp[l][rr] = (rr < wq) ? Gbig[(size_t)l * OBM + h + rr] : 0.0;
+        }
+        for (int idx = tid; idx < NB * NB; idx += 256) {             // Gp[h + l][r] = T_p(l, r)
+            const int rr = idx / NB, l = idx % NB;
+            Gp[h + l][rr] = (l <= rr && rr < wq) ? Tp[rr * NB + l] : 0.0;
+        }
+        __syncthreads();
+        double y[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cc = cg + 8 * half;
+            y[half] = (r < wq) ? Ys[h + r][cc] : 0.0;
+            if (p > 0) {
+                double sum = 0.0;
+                for (int l = 0; l < h; ++l) sum += Gp[l][r] * Ys[l][cc];
+                y[half] -= sum;
+            }
+        }
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            const double t = Gp[h + l][r];
+            w0 += t * __shfl(y[0], l, 32);
+            w1 += t * __shfl(y[1], l, 32);
+        }
+        if (r < wq) { Ys[h + r][cg] = w0; Ys[h + r][cg + 8] = w1; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ob * SOLVE_CT; idx += 256) {
+        const int row = idx % ob, c = idx / ob, col = c0 + c;
+        if (col < n2) W[(size_t)col * ldw + row] = Ys[row][c];
+    }
+}
+
+// Rows per workgroup for the many-workgroup panel kernel on an m-row matrix (0: use the single-workgroup kernel).
+static int coop_rows_per(int rows, int batch)
+{
+    if (rows < 128 || batch > 8) return 0;
+    const int gmax = (240 / batch) < CP_GMAX ? (240 / batch) : CP_GMAX;
+    int rp = rows >= 2048 ? 128 : 64;                  // measured: fewer, fatter workgroups lose to the LDS pass
+    if ((rows + rp - 1) / rp > gmax) rp = (((rows + gmax - 1) / gmax) + 7) & ~7;
+    return rp > CP_RMAX ? 0 : rp;
+}
+
+constexpr int OB = 128;          // outer block: four panels share one trailing update
+
+// out[i] = sum over slabs of part[s * strideSplit + i]
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const double *part, size_t strideSplit, int ksplit, size_t count, double *out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int k = 0; k < ksplit; ++k) s += part[(size_t)k * strideSplit + i];
+    out[i] = s;
 }
 
 __global__ void zero_strict_lower_kernel(double *Abase, int rows, int cols, int lda, size_t strideA)
@@ -196,7 +502,7 @@ static int pick_ksplit(int mp, int n2, int batch)
     // skinny product (NB x n2, K = mp): spread K so that ~512 workgroups are in flight
     const int tilesN = (n2 + 63) / 64;
     int want = 512 / (tilesN * batch > 0 ? tilesN * batch : 1);
-    int maxs = (mp + 255) / 256;                       // at least 256 rows of K per slab
+    int maxs = (mp + 127) / 128;                       // at least 128 rows of K per slab
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     if (want > 64) want = 64;
@@ -205,60 +511,237 @@ static int pick_ksplit(int mp, int n2, int batch)
 
 static int max_ksplit(int rows, int batch)
 {
-    int a = 512 / batch, b = (rows + 255) / 256;
+    int a = 512 / batch, b = (rows + 127) / 128;
     int m = a < b ? a : b;
     return m < 1 ? 1 : (m > 64 ? 64 : m);
 }
 
+// Two-level blocking applies to one tall, wide matrix: panels of 32 columns are factored and
+// applied inside an outer block of 128 columns, whose 128 reflectors then update the rest of
+// the matrix with K = 128 products (4x less trailing-matrix traffic than per-panel updates).
+static bool use_outer_blocks(int rows, int cols, int batch)
+{
+    return batch == 1 && coop_rows_per(rows, batch) > 0 && cols >= 2 * OB;
+}
+
+struct QrWs {
+    double *T, *Wpart, *W2, *slots;
+    double *Vbuf[2], *G[2], *Mo[2], *Gpart, *Wn, *Wnpart, *Wb, *Wbpart;   // outer-block path only (double-buffered per block parity)
+};
+
+static void qr_carve(void *ws, int rows, int cols, int batch, QrWs *w)
+{
+    Arena ar(ws);
+    w->T = ar.take<double>((size_t)(batch > 4 ? batch : 4) * MSTRIDE);
+    w->Wpart = ar.take<double>((size_t)batch * max_ksplit(rows, batch) * NB * (size_t)cols);
+    w->W2 = ar.take<double>((size_t)batch * NB * (size_t)cols);
+    w->slots = ar.take<double>((size_t)(batch > 8 ? 1 : batch) * 3 * CP_GMAX * CP_SLOT);
+    if (use_outer_blocks(rows, cols, batch)) {
+        for (int i = 0; i < 2; ++i) {
+            w->Vbuf[i] = ar.take<double>((size_t)rows * OB);
+            w->G[i] = ar.take<double>((size_t)OB * OB);
+            w->Mo[i] = ar.take<double>((size_t)(OB / NB) * MSTRIDE);
+        }
+        w->Gpart = ar.take<double>((size_t)64 * OB * OB);
+        w->Wn = ar.take<double>((size_t)OB * OB);
+        w->Wnpart = ar.take<double>((size_t)8 * OB * OB);
+        w->Wb = ar.take<double>((size_t)OB * cols);
+        w->Wbpart = ar.take<double>((size_t)8 * OB * cols);
+    }
+}
+
 size_t qr_ws_bytes(int rows, int cols, int batch)
 {
-    size_t t = Arena::pad((size_t)batch * NB * NB * 8);
+    size_t t = Arena::pad((size_t)(batch > 4 ? batch : 4) * MSTRIDE * 8);
     size_t wpart = Arena::pad((size_t)batch * max_ksplit(rows, batch) * NB * (size_t)cols * 8);
     size_t w2 = Arena::pad((size_t)batch * NB * (size_t)cols * 8);
-    return t + wpart + w2;
+    size_t coop = Arena::pad((size_t)(batch > 8 ? 1 : batch) * 3 * CP_GMAX * CP_SLOT * 8);
+    size_t big = 0;
+    if (use_outer_blocks(rows, cols, batch))
+        big = 2 * (Arena::pad((size_t)rows * OB * 8) + Arena::pad((size_t)OB * OB * 8) + Arena::pad((size_t)(OB / NB) * MSTRIDE * 8)) +
+              Arena::pad((size_t)64 * OB * OB * 8) + Arena::pad((size_t)OB * OB * 8) + Arena::pad((size_t)8 * OB * OB * 8) +
+              Arena::pad((size_t)OB * cols * 8) + Arena::pad((size_t)8 * OB * cols * 8);
+    return t + wpart + w2 + coop + big;
+}
+
+struct QrJob {
+    vslam_ctx *ctx;
+    double *A;
+    int rows, cols, lda;
+    size_t strideA;
+    int batch, rows_per;
+    unsigned tbase;
+    QrWs w;
+};
+
+// Factors the jb-column panel whose origin is (j, j); T goes to Tdst.  Vout (optional) receives the
+// explicit reflectors, vzero rows above the panel cleared.
+static vslam_status qr_factor_panel(QrJob &q, int j, int jb, double *Tdst, double *Vout, int ldv, int vzero)
+{
+    const int mp = q.rows - j;
+    double *P = q.A + (size_t)j * q.lda + j;
+    hipStream_t s = q.ctx->stream;
+    if (q.rows_per > 0) {
+        CoopPanelArgs ca;
+        ca.A = P; ca.lda = q.lda; ca.strideA = q.strideA; ca.mp = mp; ca.jb = jb; ca.rows_per = q.rows_per;
+        ca.G = (mp + q.rows_per - 1) / q.rows_per; ca.tbase = q.tbase;
+        ca.M = Tdst; ca.slots = q.w.slots; ca.err = q.ctx->flags;
+        ca.V = Vout; ca.ldv = ldv; ca.vzero = vzero;
+        const size_t lds = ((size_t)q.rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4) * 8;
+        hipLaunchKernelGGL(qr_panel_coop_kernel, dim3(ca.G, q.batch), dim3(CP_T), lds, s, ca);
+        q.tbase += (unsigned)jb;
+    } else {
+        if (Vout) return fail(q.ctx, VSLAM_ERR_SHAPE, "qr: explicit reflectors need a tall panel");
+        hipLaunchKernelGGL(qr_panel_kernel, dim3(q.batch), dim3(PT), 0, s, P, q.lda, q.strideA, mp, jb, Tdst);
+    }
+    VSLAM_HIP_TRY(q.ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// Applies the block reflector of the panel at (j, j) (V below the diagonal of the panel, T at Tsrc)
+// to the n2 columns that follow it.
+static vslam_status qr_apply_panel(QrJob &q, int j, int jb, const double *Tsrc, int n2)
+{
+    if (n2 <= 0) return VSLAM_OK;
+    vslam_ctx *ctx = q.ctx;
+    hipStream_t s = ctx->stream;
+    const int mp = q.rows - j, batch = q.batch;
+    double *P = q.A + (size_t)j * q.lda + j;
+    double *A2 = P + (size_t)jb * q.lda;
+    const int ksplit = pick_ksplit(mp, n2, batch);
+    const size_t slab = (size_t)NB * n2;
+    GemmDesc g1;                                   // Wpart[s] = V^T A2 over K slab s
+    g1.M = jb; g1.N = n2; g1.K = mp; g1.transA = true; g1.transB = false; g1.amode = A_UNIT_LOWER;
+    g1.A = P; g1.lda = q.lda; g1.strideA = q.strideA;
+    g1.B = A2; g1.ldb = q.lda; g1.strideB = q.strideA;
+    g1.C = q.w.Wpart; g1.ldc = NB; g1.strideC = slab * ksplit; g1.batch = batch;
+    g1.ksplit = ksplit; g1.strideSplit = slab;
+    if (ksplit == 1) { g1.C = q.w.W2; g1.strideC = slab; }   // no slabs: result goes straight to W2's buffer
+    VSLAM_TRY(gemm_f64(ctx, g1));
+    // W2 = T^T * sum slabs (ksplit == 1: in place on W2's buffer)
+    const double *src = (ksplit == 1) ? q.w.W2 : q.w.Wpart;
+    hipLaunchKernelGGL(qr_block_solve_kernel, dim3((n2 + SOLVE_CT - 1) / SOLVE_CT, batch), dim3(256), 0, s, src, slab, ksplit, NB,
+                       (ksplit == 1) ? slab : slab * ksplit, jb, n2, (const double *)nullptr, Tsrc, (size_t)MSTRIDE,
+                       q.w.W2, NB, slab);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    GemmDesc g3;                                   // A2 -= V W2
+    g3.M = mp; g3.N = n2; g3.K = jb; g3.transA = false; g3.transB = false; g3.amode = A_UNIT_LOWER;
+    g3.alpha = -1.0; g3.beta = 1.0;
+    g3.A = P; g3.lda = q.lda; g3.strideA = q.strideA;
+    g3.B = q.w.W2; g3.ldb = NB; g3.strideB = slab;
+    g3.C = A2; g3.ldc = q.lda; g3.strideC = q.strideA; g3.batch = batch;
+    return gemm_f64(ctx, g3);
+}
+
+// Applies the 128 reflectors of the block held in Vbuf/G/Mo[par] to `nc` columns starting at C
+// (rows j0.. of the matrix) on `stream`:  Y = V^T C (K-slabs) -> W = T^T Y -> C -= V W.
+static vslam_status qr_apply_outer(QrJob &q, int par, int mp0, double *C, int nc, double *W, double *Wpart, hipStream_t stream)
+{
+    if (nc <= 0) return VSLAM_OK;
+    vslam_ctx *ctx = q.ctx;
+    const int tiles = 2 * ((nc + 63) / 64);
+    int kw = 512 / tiles;
+    if (kw > mp0 / 512) kw = mp0 / 512;
+    if (kw > 8) kw = 8;
+    if (kw < 1) kw = 1;
+    const size_t count = (size_t)OB * nc;
+    GemmDesc gw;                                   // Y = V^T C (K-slabs)
+    gw.M = OB; gw.N = nc; gw.K = mp0; gw.transA = true; gw.transB = false;
+    gw.A = q.w.Vbuf[par]; gw.lda = mp0; gw.B = C; gw.ldb = q.lda;
+    gw.C = (kw == 1) ? W : Wpart; gw.ldc = OB; gw.ksplit = kw; gw.strideSplit = count;
+    VSLAM_TRY(gemm_f64_on(ctx, gw, stream));
+    hipLaunchKernelGGL(qr_block_solve_kernel, dim3((nc + SOLVE_CT - 1) / SOLVE_CT, 1), dim3(256), 0, stream,
+                       (kw == 1) ? W : Wpart, count, kw, OB, (size_t)0, OB, nc, q.w.G[par], q.w.Mo[par], (size_t)0, W, OB, (size_t)0);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    GemmDesc gu;                                   // C -= V W
+    gu.M = mp0; gu.N = nc; gu.K = OB; gu.transA = false; gu.transB = false; gu.alpha = -1.0; gu.beta = 1.0;
+    gu.A = q.w.Vbuf[par]; gu.lda = mp0; gu.B = W; gu.ldb = OB; gu.C = C; gu.ldc = q.lda;
+    return gemm_f64_on(ctx, gu, stream);
+}
+
+// One outer block of OB columns at (j0, j0), block number `blk`, parity par = blk & 1.
+// Main stream: the block's four panels; each panel's reflectors are applied at once to the columns
+// the next panels need -- the rest of this block and the whole next block.
+// Side stream: the block's 128 reflectors as one unit (Gram matrix + the panels' T) update
+// everything beyond the next block: first the 128 columns of block blk+2 ("near"), then the rest
+// ("far"), overlapping the next block's panels.
+// Events (ctx->ev): [par] reflectors of the block complete (main -> side); [2+par] near update
+// done, [4+par] far update done (side -> main).  The next block's panel applies reach into block
+// blk+2's columns, so they wait for this block's near update; the reflector buffers of a parity
+// are rewritten two blocks later, after that block's far update.
+static vslam_status qr_outer_block(QrJob &q, int j0, int blk)
+{
+    vslam_ctx *ctx = q.ctx;
+    hipStream_t s = ctx->stream;
+    const int mp0 = q.rows - j0, par = blk & 1;
+    const int reach = (j0 + 2 * OB < q.cols) ? j0 + 2 * OB : q.cols;         // panel applies stop here
+    if (blk >= 2) VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[4 + par], 0));
+    for (int p = 0; p < OB / NB; ++p) {
+        const int j = j0 + p * NB;
+        double *Tp = q.w.Mo[par] + (size_t)p * MSTRIDE;
+        VSLAM_TRY(qr_factor_panel(q, j, NB, Tp, q.w.Vbuf[par] + (size_t)p * NB * mp0 + p * NB, mp0, p * NB));
+        if (p == 0 && blk >= 1) VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[2 + (par ^ 1)], 0));
+        VSLAM_TRY(qr_apply_panel(q, j, NB, Tp, reach - (j + NB)));
+    }
+    const int nside = q.cols - reach;
+    if (nside <= 0) return VSLAM_OK;
+    hipStream_t t = ctx->side;
+    VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->ev[par], s));
+    VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(t, ctx->ev[par], 0));
+    int ks = (mp0 + 255) / 256;
+    if (ks > 64) ks = 64;
+    GemmDesc gg;                                   // Gram slabs
+    gg.M = OB; gg.N = OB; gg.K = mp0; gg.transA = true; gg.transB = false;
+    gg.A = q.w.Vbuf[par]; gg.lda = mp0; gg.B = q.w.Vbuf[par]; gg.ldb = mp0;
+    gg.C = q.w.Gpart; gg.ldc = OB; gg.ksplit = ks; gg.strideSplit = (size_t)OB * OB;
+    if (ks == 1) gg.C = q.w.G[par];
+    VSLAM_TRY(gemm_f64_on(ctx, gg, t));
+    if (ks > 1) {
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(OB * OB / 256), dim3(256), 0, t, q.w.Gpart, (size_t)OB * OB, ks, (size_t)OB * OB, q.w.G[par]);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+    }
+    double *C = q.A + (size_t)reach * q.lda + j0;
+    const int nnear = nside < OB ? nside : OB;
+    VSLAM_TRY(qr_apply_outer(q, par, mp0, C, nnear, q.w.Wn, q.w.Wnpart, t));
+    VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->ev[2 + par], t));
+    VSLAM_TRY(qr_apply_outer(q, par, mp0, C + (size_t)nnear * q.lda, nside - nnear, q.w.Wb, q.w.Wbpart, t));
+    VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->ev[4 + par], t));
+    return VSLAM_OK;
 }
 
 vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
 {
     if (rows < 1 || cols < 1 || lda < rows) return fail(ctx, VSLAM_ERR_SHAPE, "qr: bad shape %dx%d ld %d", rows, cols, lda);
     if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "qr: batch=%d out of range", batch);
-    Arena ar(ws);
-    double *T = ar.take<double>((size_t)batch * NB * NB);
-    double *Wpart = ar.take<double>((size_t)batch * max_ksplit(rows, batch) * NB * (size_t)cols);
-    double *W2 = ar.take<double>((size_t)batch * NB * (size_t)cols);
+    QrJob q;
+    q.ctx = ctx; q.A = A; q.rows = rows; q.cols = cols; q.lda = lda; q.strideA = strideA; q.batch = batch;
+    q.tbase = 0; q.rows_per = coop_rows_per(rows, batch);
+    qr_carve(ws, rows, cols, batch, &q.w);
     const int kmax = rows < cols ? rows : cols;
     hipStream_t s = ctx->stream;
-    for (int j0 = 0; j0 < kmax; j0 += NB) {
+    if (q.rows_per > 0) {
+        const size_t words = (size_t)batch * 3 * CP_GMAX * CP_SLOT * 2;
+        VSLAM_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q.w.slots), (int)CP_EMPTY32, words, s));
+        const size_t lds = ((size_t)q.rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4) * 8;
+        if (lds > 48 * 1024)
+            VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&qr_panel_coop_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    int j0 = 0;
+    if (use_outer_blocks(rows, cols, batch)) {
+        VSLAM_TRY(side_stream_init(ctx));
+        int blk = 0;
+        for (; j0 + OB <= kmax; j0 += OB, ++blk)
+            VSLAM_TRY(qr_outer_block(q, j0, blk));
+        if (blk > 0) {                                                           // join the side stream
+            VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[4], 0));
+            VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[5], 0));
+        }
+    }
+    for (; j0 < kmax; j0 += NB) {
         const int jb = (kmax - j0) < NB ? (kmax - j0) : NB;
-        const int mp = rows - j0;
-        double *P = A + (size_t)j0 * lda + j0;
-        hipLaunchKernelGGL(qr_panel_kernel, dim3(batch), dim3(PT), 0, s, P, lda, strideA, mp, jb, T);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
-        const int n2 = cols - j0 - jb;
-        if (n2 <= 0) continue;
-        double *A2 = P + (size_t)jb * lda;
-        const int ksplit = pick_ksplit(mp, n2, batch);
-        const size_t slab = (size_t)NB * n2;
-        GemmDesc g1;                                   // Wpart[s] = V^T A2 over K slab s
-        g1.M = jb; g1.N = n2; g1.K = mp; g1.transA = true; g1.transB = false; g1.amode = A_UNIT_LOWER;
-        g1.A = P; g1.lda = lda; g1.strideA = strideA;
-        g1.B = A2; g1.ldb = lda; g1.strideB = strideA;
-        g1.C = Wpart; g1.ldc = NB; g1.strideC = slab * ksplit; g1.batch = batch;
-        g1.ksplit = ksplit; g1.strideSplit = slab;
-        if (ksplit == 1) { g1.C = W2; g1.strideC = slab; }   // no slabs: result goes straight to W2's buffer
-        VSLAM_TRY(gemm_f64(ctx, g1));
-        // W2 = T^T * sum slabs (ksplit == 1: in place on W2's buffer)
-        const double *src = (ksplit == 1) ? W2 : Wpart;
-        hipLaunchKernelGGL(qr_apply_t_kernel, dim3((n2 + 255) / 256, batch), dim3(256), 0, s, T, src, slab,
-                           (ksplit == 1) ? slab : slab * ksplit, ksplit, jb, n2, NB, W2, slab);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
-        GemmDesc g3;                                   // A2 -= V W2
-        g3.M = mp; g3.N = n2; g3.K = jb; g3.transA = false; g3.transB = false; g3.amode = A_UNIT_LOWER;
-        g3.alpha = -1.0; g3.beta = 1.0;
-        g3.A = P; g3.lda = lda; g3.strideA = strideA;
-        g3.B = W2; g3.ldb = NB; g3.strideB = slab;
-        g3.C = A2; g3.ldc = lda; g3.strideC = strideA; g3.batch = batch;
-        VSLAM_TRY(gemm_f64(ctx, g3));
+        VSLAM_TRY(qr_factor_panel(q, j0, jb, q.w.T, nullptr, 0, 0));
+        VSLAM_TRY(qr_apply_panel(q, j0, jb, q.w.T, cols - j0 - jb));
     }
     dim3 grid((rows + 255) / 256, cols, batch);
     hipLaunchKernelGGL(zero_strict_lower_kernel, grid, dim3(256), 0, s, A, rows, cols, lda, strideA);
@@ -296,8 +779,7 @@ extern "C" vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int 
     VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dA, (size_t)rows * 8, A, (size_t)lda * 8, (size_t)rows * 8, cols, hipMemcpyHostToDevice, s));
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, cols, rows, 0, 1, qws));
     VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(A, (size_t)lda * 8, dA, (size_t)rows * 8, (size_t)rows * 8, cols, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
-    return VSLAM_OK;
+    return stream_finish(ctx);
 }
 
 // Test hook (not part of the public header): C = alpha*op(A)*op(B) + beta*C with host pointers.

@@ -6,21 +6,22 @@
 // (src/gaussian.cpp:34) needs one S1^-T solve.  The O(n^3) part, the prior
 // Hessian, is formed as W = S^-1 (blocked, MFMA GEMMs) followed by -W W^T
 // (one MFMA GEMM) instead of the reference's two n-column triangular solves;
-// the O(n^2) vector solves run as blocked substitution in one workgroup.
+// the O(n^2) vector solves run as blocked substitution, one launch per diagonal block.
 #include "linalg.hpp"
 
 namespace vslam {
 
 constexpr int TBK = 64;          // diagonal block of the triangular inverse
-constexpr int SB = 32;           // block of the vector solves
-constexpr int ST = 512;          // threads of the vector-solve workgroup
 
-// D = inverse of the upper-triangular jb x jb block at S (ld ldS); D written with ld TBK, zeros below.
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int jb, double *D)
+// Workgroup b inverts the upper-triangular diagonal block b (64 x 64, the last one smaller) of S;
+// D[b] (ld TBK, zeros below the diagonal) receives the inverse.  All blocks are independent.
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *Dall)
 {
     __shared__ double U[TBK][TBK + 1];
-    const int c = threadIdx.x;
-    for (int r = 0; r < jb; ++r) U[r][c] = (c < jb && r <= c) ? S[(size_t)c * ldS + r] : 0.0;
+    const int c = threadIdx.x, j0 = blockIdx.x * TBK, jb = min(TBK, n - j0);
+    const double *Sb = S + (size_t)j0 * ldS + j0;
+    double *D = Dall + (size_t)blockIdx.x * TBK * TBK;
+    for (int r = 0; r < TBK; ++r) U[r][c] = (c < jb && r <= c) ? Sb[(size_t)c * ldS + r] : 0.0;
     __syncthreads();
     // column c of the inverse by back substitution on e_c: x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r]
     double x[TBK];
@@ -55,18 +56,20 @@ __global__ void zero_lower_block_kernel(double *W, int ldW, int n)
     if (r < n && r > c) W[(size_t)c * ldW + r] = 0.0;
 }
 
-size_t trtri_ws_bytes(int n) { return Arena::pad((size_t)TBK * TBK * 8) + Arena::pad((size_t)n * TBK * 8); }
+size_t trtri_ws_bytes(int n) { return Arena::pad((size_t)((n + TBK - 1) / TBK) * TBK * TBK * 8) + Arena::pad((size_t)n * TBK * 8); }
 
 vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws)
 {
     Arena ar(ws);
-    double *D = ar.take<double>((size_t)TBK * TBK);
+    const int nblk = (n + TBK - 1) / TBK;
+    double *Dall = ar.take<double>((size_t)nblk * TBK * TBK);
     double *Tmp = ar.take<double>((size_t)n * TBK);
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, W, ldW, n);
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(64), 0, s, S, ldS, n, Dall);
     for (int j0 = 0; j0 < n; j0 += TBK) {
         const int jb = (n - j0) < TBK ? (n - j0) : TBK;
-        hipLaunchKernelGGL(trtri_diag_kernel, dim3(1), dim3(64), 0, s, S + (size_t)j0 * ldS + j0, ldS, jb, D);
+        const double *D = Dall + (size_t)(j0 / TBK) * TBK * TBK;
         hipLaunchKernelGGL(copy_block_kernel, dim3(1, jb), dim3(64), 0, s, D, TBK, W + (size_t)j0 * ldW + j0, ldW, jb, jb, 1.0);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (j0 == 0) continue;
@@ -82,80 +85,72 @@ vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, do
     return VSLAM_OK;
 }
 
-// Blocked substitution, one workgroup.  z may alias b.
-__global__ __launch_bounds__(ST) void trsv_upper_kernel(const double *S, int n, int ldS, int trans, const double *b, double *z)
+// Vector solves with the upper-triangular S, one launch per 64-wide diagonal block: every
+// workgroup solves the block redundantly (one wave, the running right-hand side passed between
+// lanes), workgroup 0 stores that part of the solution, and each workgroup then removes the block's
+// contribution from its own 256 entries of the remaining right-hand side.  z holds the right-hand
+// side on entry and the solution on return.
+//   trans = 0:  S z = b,   blocks from the last to the first, remaining entries are rows above;
+//   trans = 1:  S^T z = b, blocks from the first to the last, remaining entries are later columns.
+__global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, int ldS, int trans, int i0, int ib, double *z)
 {
-    __shared__ double red[(ST / 64) * SB];
-    __shared__ double rhs[SB], sol[SB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < n; i += ST) z[i] = b[i];
+    __shared__ double U[TBK][TBK + 1];
+    __shared__ double sol[TBK];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < TBK * TBK; idx += 256) {
+        const int r = idx % TBK, c = idx / TBK;
+        U[r][c] = (r <= c && c < ib) ? S[(size_t)(i0 + c) * ldS + i0 + r] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double v = (tid < ib) ? z[i0 + tid] : 0.0;
+        if (trans) {
+            for (int k = 0; k < ib; ++k) {
+                const double xk = __shfl(v, k, 64) / U[k][k];
+                if (tid > k) v -= U[k][tid] * xk;
+                else if (tid == k) v = xk;
+            }
+        } else {
+            for (int k = ib - 1; k >= 0; --k) {
+                const double xk = __shfl(v, k, 64) / U[k][k];
+                if (tid < k) v -= U[tid][k] * xk;
+                else if (tid == k) v = xk;
+            }
+        }
+        sol[tid] = v;
+        if (blockIdx.x == 0 && tid < ib) z[i0 + tid] = v;
+    }
     __syncthreads();
     if (trans) {
-        // S^T z = b: forward.  Block I: r = b_I - S[0:i0, I]^T z[0:i0], then the 32x32 lower solve.
-        for (int i0 = 0; i0 < n; i0 += SB) {
-            const int ib = min(SB, n - i0);
-            double acc[SB];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) acc[j] = 0.0;
-            for (int k = tid; k < i0; k += ST) {
-                const double zk = z[k];
-#pragma unroll
-                for (int j = 0; j < SB; ++j)
-                    if (j < ib) acc[j] += S[(size_t)(i0 + j) * ldS + k] * zk;
-            }
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                double v = acc[j];
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (lane == 0) red[wave * SB + j] = v;
-            }
-            __syncthreads();
-            if (tid < ib) {
-                double sum = 0.0;
-                for (int w = 0; w < ST / 64; ++w) sum += red[w * SB + tid];
-                rhs[tid] = z[i0 + tid] - sum;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int j = 0; j < ib; ++j) {
-                    double v = rhs[j];
-                    for (int l = 0; l < j; ++l) v -= S[(size_t)(i0 + j) * ldS + i0 + l] * sol[l];
-                    sol[j] = v / S[(size_t)(i0 + j) * ldS + i0 + j];
-                }
-            }
-            __syncthreads();
-            if (tid < ib) z[i0 + tid] = sol[tid];
-            __syncthreads();
+        const int c = i0 + ib + blockIdx.x * 256 + tid;             // later entry: z_c -= S[I, c]^T sol
+        if (c < n) {
+            const double *col = S + (size_t)c * ldS + i0;
+            double acc = 0.0;
+            for (int j = 0; j < ib; ++j) acc += col[j] * sol[j];
+            z[c] -= acc;
         }
     } else {
-        // S z = b: backward.  Solve the diagonal block, then z[0:i0] -= S[0:i0, I] z_I.
-        const int nblk = (n + SB - 1) / SB;
-        for (int blk = nblk - 1; blk >= 0; --blk) {
-            const int i0 = blk * SB, ib = min(SB, n - i0);
-            if (tid == 0) {
-                for (int j = ib - 1; j >= 0; --j) {
-                    double v = z[i0 + j];
-                    for (int l = j + 1; l < ib; ++l) v -= S[(size_t)(i0 + l) * ldS + i0 + j] * sol[l];
-                    sol[j] = v / S[(size_t)(i0 + j) * ldS + i0 + j];
-                }
-            }
-            __syncthreads();
-            if (tid < ib) z[i0 + tid] = sol[tid];
-            for (int r = tid; r < i0; r += ST) {
-                double v = z[r];
-#pragma unroll
-                for (int j = 0; j < SB; ++j)
-                    if (j < ib) v -= S[(size_t)(i0 + j) * ldS + r] * sol[j];
-                z[r] = v;
-            }
-            __syncthreads();
+        const int r = blockIdx.x * 256 + tid;                        // earlier entry: z_r -= S[r, I] sol
+        if (r < i0) {
+            double acc = 0.0;
+            for (int j = 0; j < ib; ++j) acc += S[(size_t)(i0 + j) * ldS + r] * sol[j];
+            z[r] -= acc;
         }
     }
 }
 
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z)
 {
-    hipLaunchKernelGGL(trsv_upper_kernel, dim3(1), dim3(ST), 0, ctx->stream, S, n, ldS, trans ? 1 : 0, b, z);
+    hipStream_t s = ctx->stream;
+    if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    const int nblk = (n + TBK - 1) / TBK;
+    for (int step = 0; step < nblk; ++step) {
+        const int blk = trans ? step : nblk - 1 - step;
+        const int i0 = blk * TBK, ib = (n - i0) < TBK ? (n - i0) : TBK;
+        const int rest = trans ? n - i0 - ib : i0;
+        const int grid = rest > 0 ? (rest + 255) / 256 : 1;
+        hipLaunchKernelGGL(trsv_step_kernel, dim3(grid), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, i0, ib, z);
+    }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
