@@ -112,17 +112,26 @@ def test_cost_joint_density(ctx, gcam, ocam, L, seed):
     assert rel_err(g, -(gp + gl)) <= TOL and rel_err(H, -(Hp + Hl)) <= TOL
 
 
+@pytest.mark.parametrize("solver", ["eig", "auto"])
 @pytest.mark.parametrize("L,seed", [(2, 41), (5, 41), (20, 7), (50, 1023)])
-def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed):
+def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     """measurementUpdateIEKF (gaussian.hpp:469-532) as called at SLAM.cpp:492.  The
     posterior mean must match the oracle's; the posterior square-root factor is
     compared through S^T S and |diag S| because its row signs follow the
     eigenvector signs of the host eigensolver (the reference has the same
-    dependence on Eigen's SelfAdjointEigenSolver)."""
+    dependence on Eigen's SelfAdjointEigenSolver).  Both routes are checked: "eig"
+    restates the reference's host loop, "auto" runs the same iteration on the device
+    from Cholesky factors; iteration and evaluation counts must agree with the oracle
+    for both."""
     from oracle import pyoracle as orc
     from visualslam_amd import api, synthetic as syn
     sc = syn.Scene(L, seed)
-    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    ctx.set_trs_solver(api.TRS_EIG if solver == "eig" else api.TRS_AUTO)
+    try:
+        ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
+    finally:
+        ctx.set_trs_solver(api.TRS_AUTO)
+    assert ctx.last_trs_route() == (api.TRS_EIG if solver == "eig" else api.TRS_AUTO)
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
     assert ret == 0 and ret0 == 0
     assert (iters, evals) == (iters0, evals0)
@@ -136,3 +145,40 @@ def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed):
     V1, g1, H1 = api.cost_joint_density(ctx, gcam, mup, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
     assert V1 <= V0
     assert rel_err(np.linalg.inv(Sp.T @ Sp), H1) <= 1e-6
+
+
+def test_measurement_update_iekf_indefinite_falls_back(ctx, gcam, ocam):
+    """A start far from the optimum with a loose prior makes the exact likelihood Hessian indefinite:
+    the device route hands over to the eigenvalue route and the result still matches the oracle."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(6, 3)
+    S = np.diag(np.concatenate([np.full(6, 0.1), np.full(6, 0.5), np.full(18, 5.0)]))
+    rng = np.random.default_rng(2)
+    mu = sc.x + np.concatenate([np.zeros(6), 0.05 * rng.standard_normal(6), 0.8 * rng.standard_normal(18)])
+    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
+    ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(mu, S, sc.y, sc.visible, ocam, sc.sigma)
+    assert ctx.last_trs_route() == api.TRS_EIG
+    assert (ret, iters, evals) == (ret0, iters0, evals0)
+    assert np.max(np.abs(mup - mup0) / np.maximum(np.abs(mup0), 1e-3)) <= 1e-6
+    assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-6
+
+
+def test_measurement_update_iekf_2000_landmarks(ctx, gcam):
+    """The 2,000-landmark update (state dimension 6012) runs entirely on the device.  Checked through
+    properties that do not need a CPU run of the same size: the posterior mean is a stationary point of
+    the joint cost, the cost went down, and S^T S is the inverse of the Hessian there."""
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(2000, 42, dense_S=True)
+    rng = np.random.default_rng(5)
+    mu = sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * sc.L)])
+    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    assert ret == 0 and ctx.last_trs_route() == api.TRS_AUTO
+    assert not np.tril(Sp, -1).any()
+    V0, g0, _ = api.cost_joint_density(ctx, gcam, mu, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    V1, g1, H1 = api.cost_joint_density(ctx, gcam, mup, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    assert V1 < V0
+    assert np.linalg.norm(g1) <= 1e-7 * np.linalg.norm(g0)
+    probe = rng.standard_normal((sc.n, 4))
+    back = Sp.T @ (Sp @ (H1 @ probe))                       # (S^T S) H = I on random probes
+    assert rel_err(back, probe) <= 1e-8

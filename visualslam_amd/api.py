@@ -16,6 +16,9 @@ LAYOUT_COMPAT, LAYOUT_STRICT = 0, 1
 HARRIS, SHI_TOMASI = 0, 1
 
 
+TRS_AUTO, TRS_EIG = 0, 1
+
+
 class Context:
     """One device context (one HIP stream).  stream: a raw hipStream_t handle
     (e.g. torch.cuda.current_stream().cuda_stream) to borrow, or None to own one."""
@@ -31,6 +34,13 @@ class Context:
             raise VslamError("cannot create a context on device %d: %s (status %d); libvslam_hip needs a gfx950 GPU"
                              % (device, self._L.vslam_status_string(st).decode(), st))
         self.device = device
+
+    def set_trs_solver(self, solver):
+        """TRS_AUTO (device Cholesky route, eigenvalue fallback) or TRS_EIG (reference's host eigenvalue route)."""
+        check(self._L.vslam_ctx_set_trs_solver(self.ptr, int(solver)), self.ptr)
+
+    def last_trs_route(self):
+        return int(self._L.vslam_ctx_last_trs_route(self.ptr))
 
     def synchronize(self):
         check(self._L.vslam_ctx_synchronize(self.ptr), self.ptr)

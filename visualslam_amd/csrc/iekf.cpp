@@ -1,8 +1,10 @@
-// Host driver of the iterated-EKF measurement update: the trust-region Newton
-// loop and the Moré-Sorensen subproblem stay on the host (as in the reference,
-// src/fmin.hpp:19-107 and src/fmin.cpp:40-131) and drive the device kernels for
-// the cost, gradient, Hessian and the posterior square-root QR
-// (src/gaussian.hpp:469-532).
+// Driver of the iterated-EKF measurement update (src/gaussian.hpp:469-532).
+// Default route (VSLAM_TRS_AUTO): the whole trust-region Newton iteration runs on the
+// device from Cholesky factors (newton.hip).  Eigenvalue route (VSLAM_TRS_EIG, and the
+// fallback when a Hessian is not positive definite): the loop and the Moré-Sorensen
+// subproblem run on the host exactly as in the reference (src/fmin.hpp:19-107,
+// src/fmin.cpp:40-131) and drive the device kernels for the cost, gradient, Hessian
+// and the posterior square-root QR.
 //
 // The symmetric eigendecomposition the loop needs (Eigen::SelfAdjointEigenSolver
 // in the reference, src/fmin.hpp:42-44,99-101) is done here by Householder
@@ -180,6 +182,16 @@ int trs_host(const double *Q, const double *v, const double *g, int n, double D,
 
 using namespace vslam;
 
+extern "C" vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (solver != VSLAM_TRS_AUTO && solver != VSLAM_TRS_EIG) return fail(ctx, VSLAM_ERR_ARG, "set_trs_solver: unknown solver %d", solver);
+    ctx->trs_solver = solver;
+    return VSLAM_OK;
+}
+
+extern "C" int vslam_ctx_last_trs_route(const vslam_ctx *ctx) { return ctx ? ctx->trs_last : -1; }
+
 extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out);
 
 extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *cam,
@@ -195,7 +207,8 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n)));
+    const bool try_device = ctx->trs_solver == VSLAM_TRS_AUTO;
+    VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n) + (try_device ? newton_ws_bytes(n) : 0)));
     CostDevice c;
     cost_carve(ctx->ws, n, &c);
     hipStream_t s = ctx->stream;
@@ -205,6 +218,21 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.y, y, 2 * c.L * 8, hipMemcpyHostToDevice, s));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.vis, visible, c.L, hipMemcpyHostToDevice, s));
 
+    if (try_device) {
+        int code = 1, it = 0, ev = 0, status = 0;
+        VSLAM_TRY(iekf_newton_device(ctx, k, sigma, &c, static_cast<char *>(ctx->ws) + cost_ws_bytes(n), mu_post, S_post, ldSp,
+                                     &code, &it, &ev, &status));
+        if (status == 0) {
+            ctx->trs_last = VSLAM_TRS_AUTO;
+            if (fmin_code) *fmin_code = code;
+            if (iters) *iters = it;
+            if (cost_evals) *cost_evals = ev;
+            return VSLAM_OK;
+        }
+        c.prior_ready = false;      // the device route used the prior-Hessian buffers as scratch
+    }
+
+    ctx->trs_last = VSLAM_TRS_EIG;
     int evals = 0;
     auto cost = [&](const std::vector<double> &x, std::vector<double> &g, std::vector<double> &H, double *f) -> vslam_status {
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.x, x.data(), n * 8, hipMemcpyHostToDevice, s));

@@ -8,6 +8,25 @@
 
 namespace vslam {
 
+#ifdef __HIPCC__
+// acc - sum_{l in [l0, l1)} a[l * sa] * b[l * sb] with the loads of eight terms in flight at a time
+// (the callers run one wave per workgroup, so nothing else hides the LDS latency).
+__device__ __forceinline__ double lds_dot_sub(double acc, const double *a, int sa, const double *b, int sb, int l0, int l1)
+{
+    double s0 = acc, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int l = l0;
+    for (; l + 8 <= l1; l += 8) {
+        double u[8], x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u[j] = a[(l + j) * sa]; x[j] = b[(l + j) * sb]; }
+        s0 -= u[0] * x[0]; s1 -= u[1] * x[1]; s2 -= u[2] * x[2]; s3 -= u[3] * x[3];
+        s0 -= u[4] * x[4]; s1 -= u[5] * x[5]; s2 -= u[6] * x[6]; s3 -= u[7] * x[7];
+    }
+    for (; l < l1; ++l) s0 -= a[l * sa] * b[l * sb];
+    return (s0 + s1) + (s2 + s3);
+}
+#endif
+
 // How the A operand of a GEMM is read from memory.
 enum AMode {
     A_PLAIN = 0,
@@ -61,5 +80,16 @@ struct CostDevice {
 size_t cost_ws_bytes(int n);
 void cost_carve(void *ws, int n, CostDevice *c);
 vslam_status cost_eval_dev(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c);
+
+
+// Device-resident trust-region Newton iteration + posterior square root of the IEKF update
+// (newton.hip).  `ws` holds newton_ws_bytes(n) bytes beyond the CostDevice carve-up; *status_out
+// is 0 when the results were produced, 1 when an iterate's Hessian was not positive definite
+// (outputs are then meaningless and the caller takes the eigenvalue route).
+size_t newton_ws_bytes(int n);
+vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
+vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
+                                double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
+                                int *status_out);
 
 }  // namespace vslam

@@ -1,0 +1,309 @@
+// Device-resident trust-region Newton iteration of the iterated-EKF measurement update.
+//
+// The reference's fminNewtonTrustEig (src/fmin.hpp:19-107) takes an eigendecomposition of the
+// Hessian at every accepted iterate and solves the trust-region subproblem in the eigenbasis
+// (src/fmin.cpp:40-131): p(lam) = -(H + lam I)^-1 g, with Newton's method on
+// 1/Delta - 1/|p(lam)| when the full step leaves the region.  When H is positive definite the
+// same quantities follow from Cholesky factors H + lam I = U^T U:
+//     p = -U^-1 U^-T g,      p^T (H + lam I)^-1 p = |U^-T p|^2,
+// so the iteration below produces the reference's sequence of lam (start 0, lower clamp 0, same
+// update and stopping rule) without an eigensolver; everything stays in HBM and only a handful of
+// scalars cross PCIe per iteration.  An iterate whose Hessian is not positive definite is handed
+// back to the caller, which takes the eigenvalue route for it.
+//
+// The posterior square-root covariance (src/gaussian.hpp:513-516: S = triu(qr(diag(v^-1/2) Q^T)),
+// i.e. S^T S = H^-1) is formed as the R factor of U^-T:  U^-1 U^-T = H^-1.  It equals the
+// reference's S up to the signs of its rows, which there depend on the eigensolver's choice of
+// eigenvector signs.
+#include "linalg.hpp"
+
+#include <cmath>
+#include <limits>
+
+namespace vslam {
+
+constexpr int CB = 64;           // Cholesky block
+
+// Upper Cholesky of the jb x jb diagonal block at (j0, j0), one wave, in LDS: row k of U from the
+// rows above it, lane j owning column j:  U[k][j] = (A[k][j] - sum_{l<k} U[l][k] U[l][j]) / U[k][k].
+// Only the upper triangle is read and written.  A non-positive pivot stores its 1-based column in
+// *info (first one wins); the arithmetic carries on with NaNs.
+constexpr int CLD = CB + 1;
+__global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info)
+{
+    __shared__ double U[CB * CLD];
+    const int lane = threadIdx.x;
+    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (lane <= cb + j && cb + j < jb) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) U[lane * CLD + cb + j] = v[j];
+    }
+    __syncthreads();
+    for (int k = 0; k < jb; ++k) {
+        const double num = lds_dot_sub(U[k * CLD + lane], U + k, CLD, U + lane, CLD, 0, k);
+        const double dkk = __shfl(num, k, 64);
+        if (lane == k && !(dkk > 0.0)) atomicCAS(info, 0, j0 + k + 1);
+        const double d = sqrt(dkk);
+        __syncthreads();
+        if (lane >= k) U[k * CLD + lane] = (lane == k) ? d : num / d;
+        __syncthreads();
+    }
+#pragma unroll 8
+    for (int c = 0; c < jb; ++c)
+        if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * CLD + c];
+}
+
+// Row panel of the factor: X = U_JJ^-T * A[J, rest] in place.  A workgroup (one wave) owns 64
+// columns; lane = column, forward substitution x_k = (b_k - sum_{l<k} U[l][k] x_l) / U[k][k] with
+// both operands in LDS.
+__global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int n, int j0)
+{
+    extern __shared__ double potrf_lds[];
+    double *U = potrf_lds;                 // [CB][CLD]
+    double *X = potrf_lds + CB * CLD;      // [CB][CLD], X[k][col]
+    const int lane = threadIdx.x;
+    const int c0 = j0 + CB + blockIdx.x * CB, nc = min(CB, n - c0);
+    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 32 in flight
+        double u[16], x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            u[j] = (lane <= cb + j) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
+            x[j] = (cb + j < nc) ? A[(size_t)(c0 + cb + j) * lda + j0 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { U[lane * CLD + cb + j] = u[j]; X[lane * CLD + cb + j] = x[j]; }
+    }
+    __syncthreads();
+    for (int k = 0; k < CB; ++k) {
+        X[k * CLD + lane] = lds_dot_sub(X[k * CLD + lane], U + k, CLD, X + lane, CLD, 0, k) / U[k * CLD + k];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < nc; ++c) A[(size_t)(c0 + c) * lda + j0 + lane] = X[lane * CLD + c];
+}
+
+__global__ void add_diag_kernel(double *A, int lda, int n, double lam)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * lda + i] += lam;
+}
+
+__global__ void zero_below_diag_kernel(double *A, int lda, int n)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (r < n && r > c) A[(size_t)c * lda + r] = 0.0;
+}
+
+// In-place upper Cholesky A = U^T U of the symmetric n x n matrix in A (both triangles are
+// overwritten: U above, zeros below).  *info (device) must be 0 on entry.
+vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info)
+{
+    hipStream_t s = ctx->stream;
+    const size_t lds = (size_t)2 * CB * CLD * 8;
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int j0 = 0; j0 < n; j0 += CB) {
+        const int jb = (n - j0) < CB ? (n - j0) : CB;
+        hipLaunchKernelGGL(potf2_upper_kernel, dim3(1), dim3(64), 0, s, A, lda, j0, jb, info);
+        const int rest = n - j0 - jb;
+        if (rest <= 0) break;
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB), dim3(64), lds, s, A, lda, n, j0);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        GemmDesc g;                                   // A[rest, rest] -= X^T X
+        g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0;
+        g.A = A + (size_t)(j0 + jb) * lda + j0; g.lda = lda;
+        g.B = g.A; g.ldb = lda;
+        g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda;
+        VSLAM_TRY(gemm_f64(ctx, g));
+    }
+    hipLaunchKernelGGL(zero_below_diag_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, A, lda, n);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.
+struct DotArgs { const double *a[4]; const double *b[4]; };
+__global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *out)
+{
+    __shared__ double red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < n; i += 1024)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (d.a[q]) acc[q] += d.a[q][i] * d.b[q][i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = acc[q];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[q][wave] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double sum = 0.0;
+        for (int w = 0; w < 16; ++w) sum += red[tid][w];
+        out[tid] = sum;
+    }
+}
+
+__global__ void axpby_kernel(double a, const double *x, double b, const double *y, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const double *A, int n, double *B)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + tx, c = by + j;
+        tile[j][tx] = (r < n && c < n) ? A[(size_t)c * n + r] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + tx, c = bx + j;                    // B(r, c) = A(c, r)
+        if (r < n && c < n) B[(size_t)c * n + r] = tile[tx][j];
+    }
+}
+
+size_t newton_ws_bytes(int n)
+{
+    const size_t nn = (size_t)n * n;
+    return 2 * Arena::pad(nn * 8) + 8 * Arena::pad((size_t)n * 8) + Arena::pad(64) + Arena::pad(64) + qr_ws_bytes(n, n, 1);
+}
+
+namespace {
+struct NewtonDevice {
+    double *U, *Hcur, *gcur, *xcur, *p, *t, *q, *xn, *Hp, *spare, *dots;
+    int *info;
+    void *qws;
+};
+void newton_carve(void *ws, int n, NewtonDevice *w)
+{
+    Arena ar(ws);
+    const size_t nn = (size_t)n * n;
+    w->U = ar.take<double>(nn); w->Hcur = ar.take<double>(nn);
+    w->gcur = ar.take<double>(n); w->xcur = ar.take<double>(n); w->p = ar.take<double>(n); w->t = ar.take<double>(n);
+    w->q = ar.take<double>(n); w->xn = ar.take<double>(n); w->Hp = ar.take<double>(n); w->spare = ar.take<double>(n);
+    w->dots = ar.take<double>(8);
+    w->info = ar.take<int>(16);
+    w->qws = ar.take<char>(qr_ws_bytes(n, n, 1));
+}
+}  // namespace
+
+// Runs the whole update on the device.  On return *status_out is
+//   0  finished: mu_post (host) and S_post (host, ld ldSp) hold the result, fmin_code/iters/evals set;
+//   1  an iterate's Hessian was not positive definite: the outputs are meaningless and the caller
+//      should take the eigenvalue route from the start.
+vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
+                                double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
+                                int *status_out)
+{
+    const int n = c->n;
+    const size_t nn = (size_t)n * n;
+    hipStream_t s = ctx->stream;
+    NewtonDevice w;
+    newton_carve(ws, n, &w);
+    const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
+    const int nb = (n + 255) / 256;
+    int evals = 0;
+    double hd[4];
+    int hinfo = 0;
+    *status_out = 0;
+
+    auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
+        DotArgs d;
+        d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = nullptr; d.b[3] = nullptr;
+        hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(hd, w.dots, 4 * 8, hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(&hinfo, w.info, sizeof(int), hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        return VSLAM_OK;
+    };
+    // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
+    auto factor_and_step = [&](double lam) -> vslam_status {
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
+        if (lam != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(nb), dim3(256), 0, s, w.U, n, n, lam);
+        VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.gcur, w.t));
+        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p));
+        hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, -1.0, w.p, 0.0, (const double *)nullptr, w.p, n);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        return VSLAM_OK;
+    };
+    auto eval_at = [&](const double *x, double *f) -> vslam_status {
+        if (x != c->x) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c->x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        VSLAM_TRY(cost_eval_dev(ctx, k, sigma, c));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(f, c->vals + 2, 8, hipMemcpyDeviceToHost, s));
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        ++evals;
+        return VSLAM_OK;
+    };
+    auto accept = [&]() -> vslam_status {                    // current iterate := the point just evaluated
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.xcur, c->x, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.gcur, c->g, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.Hcur, c->H, nn * 8, hipMemcpyDeviceToDevice, s));
+        return VSLAM_OK;
+    };
+
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, 16 * sizeof(int), s));
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c->x, c->mu, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    double f = 0.0, fn = 0.0, Delta = 1e0;
+    VSLAM_TRY(eval_at(c->x, &f));                                        // src/fmin.hpp:39
+    VSLAM_TRY(accept());
+    int ret = 1, it;
+    for (it = 0; it < 50; ++it) {
+        // ---- trust-region subproblem, src/fmin.cpp:40-131 with l1 > 0 ----
+        double lam = 0.0;
+        VSLAM_TRY(factor_and_step(lam));
+        VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
+        if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
+        double pn = std::sqrt(hd[0]);
+        if (pn > Delta) {
+            for (int kk = 0; kk < 20; ++kk) {
+                VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.p, w.q));
+                VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
+                const double ppn = std::sqrt(hd[0]), dpp = hd[1];
+                const double ff = 1 / Delta - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);   // d|p|/dlam = -p'(H+lam I)^-1 p / |p|
+                lam = std::max(0.0, lam - ff / gg);
+                VSLAM_TRY(factor_and_step(lam));
+                if (std::fabs(ff) < sqrteps) break;
+            }
+        }
+        // ---- src/fmin.hpp:54-105 ----
+        GemmDesc gv;                                   // Hp = Hcur * p
+        gv.M = n; gv.N = 1; gv.K = n; gv.transA = false; gv.transB = false;
+        gv.A = w.Hcur; gv.lda = n; gv.B = w.p; gv.ldb = n; gv.C = w.Hp; gv.ldc = n;
+        VSLAM_TRY(gemm_f64(ctx, gv));
+        hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n);
+        VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hp, w.p, w.p));
+        if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
+        const double pg = hd[0], pHp = hd[1];
+        pn = std::sqrt(hd[2]);
+        if (std::fabs(-pg) < 2 * eps) { ret = 0; break; }
+        VSLAM_TRY(eval_at(w.xn, &fn));
+        const double dm = -pg - 0.5 * pHp, rho = (f - fn) / dm;
+        if (rho < 0.1) Delta = 0.25 * pn;
+        else if (rho > 0.75 && pn > 0.8 * Delta) Delta = 2.0 * Delta;
+        if (rho >= 0.001) { f = fn; VSLAM_TRY(accept()); }
+    }
+    // ---- posterior: S = R factor of U^-T with U^T U = H at the final iterate ----
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
+    VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+    VSLAM_TRY(trtri_upper_dev(ctx, w.U, n, n, c->Hl, n, c->tws));        // Hl, W: scratch from here on
+    hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, c->Hl, n, c->W);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(qr_upper_dev(ctx, c->W, n, n, n, 0, 1, w.qws));
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(&hinfo, w.info, sizeof(int), hipMemcpyDeviceToHost, s));
+    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mu_post, w.xcur, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(stream_finish(ctx));
+    if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
+    *fmin_code = ret; *iters = it; *evals_out = evals;
+    return VSLAM_OK;
+}
+
+}  // namespace vslam

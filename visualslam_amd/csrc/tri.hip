@@ -13,35 +13,36 @@ namespace vslam {
 
 constexpr int TBK = 64;          // diagonal block of the triangular inverse
 
-// Workgroup b inverts the upper-triangular diagonal block b (64 x 64, the last one smaller) of S;
-// D[b] (ld TBK, zeros below the diagonal) receives the inverse.  All blocks are independent.
+// Workgroup b (one wave) inverts the upper-triangular diagonal block b (64 x 64, the last one
+// smaller) of S; D[b] (ld TBK, zeros below the diagonal) receives the inverse.  Lane c owns column
+// c of the inverse and back-substitutes e_c:  x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r];
+// both matrices live in LDS (U read as broadcasts, the inverse lane-contiguous).
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *Dall)
 {
-    __shared__ double U[TBK][TBK + 1];
+    extern __shared__ double trtri_lds[];
+    double *U = trtri_lds;                        // [TBK][TBK + 1]
+    double *X = trtri_lds + TBK * (TBK + 1);      // [TBK][TBK], X[r][c]
     const int c = threadIdx.x, j0 = blockIdx.x * TBK, jb = min(TBK, n - j0);
     const double *Sb = S + (size_t)j0 * ldS + j0;
     double *D = Dall + (size_t)blockIdx.x * TBK * TBK;
-    for (int r = 0; r < TBK; ++r) U[r][c] = (c < jb && r <= c) ? Sb[(size_t)c * ldS + r] : 0.0;
-    __syncthreads();
-    // column c of the inverse by back substitution on e_c: x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r]
-    double x[TBK];
+    for (int cb = 0; cb < TBK; cb += 16) {        // lane = row: coalesced column reads, 16 in flight
+        double v[16];
 #pragma unroll
-    for (int r = 0; r < TBK; ++r) x[r] = 0.0;
-    if (c < jb) {
-#pragma unroll
-        for (int r = TBK - 1; r >= 0; --r) {
-            if (r <= c && r < jb) {
-                double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < TBK; ++k)
-                    if (k > r && k <= c) s -= U[r][k] * x[k];
-                x[r] = s / U[r][r];
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int cc = cb + j;
+            v[j] = (c <= cc && cc < jb) ? Sb[(size_t)cc * ldS + c] : ((c == cc) ? 1.0 : 0.0);
         }
-    }
 #pragma unroll
-    for (int r = 0; r < TBK; ++r)
-        if (c < TBK) D[(size_t)c * TBK + r] = (c < jb && r <= c) ? x[r] : 0.0;
+        for (int j = 0; j < 16; ++j) U[c * (TBK + 1) + cb + j] = v[j];
+    }
+    __syncthreads();
+    for (int r = TBK - 1; r >= 0; --r) {
+        const double num = lds_dot_sub((r == c) ? 1.0 : 0.0, U + r * (TBK + 1), 1, X + c, TBK, r + 1, TBK);
+        X[r * TBK + c] = (r <= c) ? num / U[r * (TBK + 1) + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < TBK; ++r) D[(size_t)c * TBK + r] = (c < jb && r <= c) ? X[r * TBK + c] : 0.0;
 }
 
 __global__ void copy_block_kernel(const double *src, int lds, double *dst, int ldd, int rows, int cols, double scale)
@@ -66,7 +67,9 @@ vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, do
     double *Tmp = ar.take<double>((size_t)n * TBK);
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, W, ldW, n);
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(64), 0, s, S, ldS, n, Dall);
+    const size_t dlds = (size_t)(TBK * (TBK + 1) + TBK * TBK) * 8;
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(64), dlds, s, S, ldS, n, Dall);
     for (int j0 = 0; j0 < n; j0 += TBK) {
         const int jb = (n - j0) < TBK ? (n - j0) : TBK;
         const double *D = Dall + (size_t)(j0 / TBK) * TBK * TBK;
@@ -97,9 +100,18 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
     __shared__ double U[TBK][TBK + 1];
     __shared__ double sol[TBK];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < TBK * TBK; idx += 256) {
-        const int r = idx % TBK, c = idx / TBK;
-        U[r][c] = (r <= c && c < ib) ? S[(size_t)(i0 + c) * ldS + i0 + r] : 0.0;
+    {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = tid + 256 * j, r = idx % TBK, c = idx / TBK;
+            v[j] = (r <= c && c < ib) ? S[(size_t)(i0 + c) * ldS + i0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = tid + 256 * j;
+            U[idx % TBK][idx / TBK] = v[j];
+        }
     }
     __syncthreads();
     if (tid < 64) {
