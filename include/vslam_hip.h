@@ -175,15 +175,16 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
                                            int32_t *fmin_code, int32_t *iters, int32_t *cost_evals);
 
 /* How vslam_measurement_update_iekf solves the trust-region subproblem of src/fmin.cpp:40-131.
- * EIG: as the reference, from a symmetric eigendecomposition of the Hessian taken on the host at
- *      every accepted iterate (O(n^3) scalar work per iterate).
- * AUTO (default): while the Hessian is positive definite, from Cholesky factors on the device --
- *      the same secular-equation Newton iteration, no eigensolver; the posterior square root is
- *      the R factor of U^-T (equal to the reference's up to row signs).  Falls back to EIG for an
- *      update that meets an indefinite Hessian.  No counterpart in the reference. */
-enum { VSLAM_TRS_AUTO = 0, VSLAM_TRS_EIG = 1 };
+ * EIG (default): as the reference, from a symmetric eigendecomposition of the Hessian taken on
+ *      the host at every accepted iterate (O(n^3) scalar work per iterate).
+ * CHOLESKY (opt-in, no counterpart in the reference): while the Hessian is positive definite,
+ *      from Cholesky factors on the device -- the same secular-equation Newton iteration with
+ *      the same iterates, no eigensolver; the posterior square root is the R factor of U^-T
+ *      (equal to the reference's up to row signs).  An update that meets an indefinite Hessian
+ *      is redone on the EIG route. */
+enum { VSLAM_TRS_EIG = 0, VSLAM_TRS_CHOLESKY = 1 };
 vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver);
-/* Route the context's last measurement update actually took (VSLAM_TRS_AUTO = device Cholesky,
+/* Route the context's last measurement update actually took (VSLAM_TRS_CHOLESKY = device route,
  * VSLAM_TRS_EIG = host eigenvalue route), -1 before the first update.  Diagnostic. */
 int vslam_ctx_last_trs_route(const vslam_ctx *ctx);
 

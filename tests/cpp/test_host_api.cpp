@@ -208,6 +208,18 @@ static void test_measurement_update(const std::string &xml)
     double gn = 0.0, scale = 0.0;
     for (int i = 0; i < n; ++i) { gn += (gl(i) + gp(i)) * (gl(i) + gp(i)); scale += gl(i) * gl(i) + gp(i) * gp(i); }
     CHECK_TRUE(std::sqrt(gn) <= 1e-6 * (1.0 + std::sqrt(scale)));
+    // The opt-in device route reaches the same posterior (S up to row signs: compare S^T S on the diagonal).
+    Vector mu2; Matrix S2;
+    useDeviceTrustRegion(true);
+    int code2 = measurementUpdateIEKF(sc.mu, sc.S, u, y, PointLogLikelihood(), sc.param, mu2, S2);
+    useDeviceTrustRegion(false);
+    CHECK_TRUE(code2 == 0);
+    for (int j = 0; j < n; ++j) {
+        CHECK_NEAR(mu2(j), muxGy(j), 1e-7);
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i <= j; ++i) { a += S2(i, j) * S2(i, j); b += SxxGy(i, j) * SxxGy(i, j); }
+        CHECK_NEAR(a, b, 1e-7);
+    }
     // The update does not inflate any marginal variance: diag(Spost' Spost) <= diag(S' S).
     for (int j = 0; j < n; ++j) {
         double a = 0.0, b = 0.0;

@@ -112,7 +112,7 @@ def test_cost_joint_density(ctx, gcam, ocam, L, seed):
     assert rel_err(g, -(gp + gl)) <= TOL and rel_err(H, -(Hp + Hl)) <= TOL
 
 
-@pytest.mark.parametrize("solver", ["eig", "auto"])
+@pytest.mark.parametrize("solver", ["eig", "cholesky"])
 @pytest.mark.parametrize("L,seed", [(2, 41), (5, 41), (20, 7), (50, 1023)])
 def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     """measurementUpdateIEKF (gaussian.hpp:469-532) as called at SLAM.cpp:492.  The
@@ -120,18 +120,18 @@ def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     compared through S^T S and |diag S| because its row signs follow the
     eigenvector signs of the host eigensolver (the reference has the same
     dependence on Eigen's SelfAdjointEigenSolver).  Both routes are checked: "eig"
-    restates the reference's host loop, "auto" runs the same iteration on the device
+    restates the reference's host loop, "cholesky" runs the same iteration on the device
     from Cholesky factors; iteration and evaluation counts must agree with the oracle
     for both."""
     from oracle import pyoracle as orc
     from visualslam_amd import api, synthetic as syn
     sc = syn.Scene(L, seed)
-    ctx.set_trs_solver(api.TRS_EIG if solver == "eig" else api.TRS_AUTO)
+    ctx.set_trs_solver(api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
     try:
         ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
     finally:
-        ctx.set_trs_solver(api.TRS_AUTO)
-    assert ctx.last_trs_route() == (api.TRS_EIG if solver == "eig" else api.TRS_AUTO)
+        ctx.set_trs_solver(api.TRS_EIG)
+    assert ctx.last_trs_route() == (api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
     assert ret == 0 and ret0 == 0
     assert (iters, evals) == (iters0, evals0)
@@ -156,7 +156,11 @@ def test_measurement_update_iekf_indefinite_falls_back(ctx, gcam, ocam):
     S = np.diag(np.concatenate([np.full(6, 0.1), np.full(6, 0.5), np.full(18, 5.0)]))
     rng = np.random.default_rng(2)
     mu = sc.x + np.concatenate([np.zeros(6), 0.05 * rng.standard_normal(6), 0.8 * rng.standard_normal(18)])
-    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
+    ctx.set_trs_solver(api.TRS_CHOLESKY)
+    try:
+        ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
+    finally:
+        ctx.set_trs_solver(api.TRS_EIG)
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(mu, S, sc.y, sc.visible, ocam, sc.sigma)
     assert ctx.last_trs_route() == api.TRS_EIG
     assert (ret, iters, evals) == (ret0, iters0, evals0)
@@ -165,15 +169,19 @@ def test_measurement_update_iekf_indefinite_falls_back(ctx, gcam, ocam):
 
 
 def test_measurement_update_iekf_2000_landmarks(ctx, gcam):
-    """The 2,000-landmark update (state dimension 6012) runs entirely on the device.  Checked through
+    """The 2,000-landmark update (state dimension 6012) on the opt-in device route.  Checked through
     properties that do not need a CPU run of the same size: the posterior mean is a stationary point of
     the joint cost, the cost went down, and S^T S is the inverse of the Hessian there."""
     from visualslam_amd import api, synthetic as syn
     sc = syn.Scene(2000, 42, dense_S=True)
     rng = np.random.default_rng(5)
     mu = sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * sc.L)])
-    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, sc.S, sc.y, sc.visible, sc.sigma)
-    assert ret == 0 and ctx.last_trs_route() == api.TRS_AUTO
+    ctx.set_trs_solver(api.TRS_CHOLESKY)
+    try:
+        ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, sc.S, sc.y, sc.visible, sc.sigma)
+    finally:
+        ctx.set_trs_solver(api.TRS_EIG)
+    assert ret == 0 and ctx.last_trs_route() == api.TRS_CHOLESKY
     assert not np.tril(Sp, -1).any()
     V0, g0, _ = api.cost_joint_density(ctx, gcam, mu, mu, sc.S, sc.y, sc.visible, sc.sigma)
     V1, g1, H1 = api.cost_joint_density(ctx, gcam, mup, mu, sc.S, sc.y, sc.visible, sc.sigma)

@@ -15,8 +15,8 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     sc = syn.Scene(L, 42, dense_S=True)
     ctx = api.Context(0)
-    if "--eig" in sys.argv:
-        ctx.set_trs_solver(api.TRS_EIG)
+    if "--eig" not in sys.argv:
+        ctx.set_trs_solver(api.TRS_CHOLESKY)
     cam = api.camera_from_xml(syn.CAMERA_XML)
     rng = np.random.default_rng(5)
     mu = sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)])

@@ -16,7 +16,7 @@ LAYOUT_COMPAT, LAYOUT_STRICT = 0, 1
 HARRIS, SHI_TOMASI = 0, 1
 
 
-TRS_AUTO, TRS_EIG = 0, 1
+TRS_EIG, TRS_CHOLESKY = 0, 1
 
 
 class Context:
@@ -36,7 +36,7 @@ class Context:
         self.device = device
 
     def set_trs_solver(self, solver):
-        """TRS_AUTO (device Cholesky route, eigenvalue fallback) or TRS_EIG (reference's host eigenvalue route)."""
+        """TRS_EIG (default: the reference's host eigenvalue route) or TRS_CHOLESKY (device route, eigenvalue fallback)."""
         check(self._L.vslam_ctx_set_trs_solver(self.ptr, int(solver)), self.ptr)
 
     def last_trs_route(self):

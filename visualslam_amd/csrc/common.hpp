@@ -25,7 +25,7 @@ struct vslam_ctx {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose barrier gave up
     int *flags_host = nullptr;   // pinned mirror read by stream_finish
-    int trs_solver = 0;          // VSLAM_TRS_AUTO / VSLAM_TRS_EIG
+    int trs_solver = 0;          // VSLAM_TRS_EIG (default) / VSLAM_TRS_CHOLESKY
     int trs_last = -1;           // route the last measurement update took (-1: none yet)
     char err[512] = {0};
 };

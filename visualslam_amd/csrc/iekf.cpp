@@ -1,10 +1,10 @@
 // Driver of the iterated-EKF measurement update (src/gaussian.hpp:469-532).
-// Default route (VSLAM_TRS_AUTO): the whole trust-region Newton iteration runs on the
-// device from Cholesky factors (newton.hip).  Eigenvalue route (VSLAM_TRS_EIG, and the
-// fallback when a Hessian is not positive definite): the loop and the Moré-Sorensen
+// Default route (VSLAM_TRS_EIG): the trust-region Newton loop and the Moré-Sorensen
 // subproblem run on the host exactly as in the reference (src/fmin.hpp:19-107,
 // src/fmin.cpp:40-131) and drive the device kernels for the cost, gradient, Hessian
-// and the posterior square-root QR.
+// and the posterior square-root QR.  Opt-in route (VSLAM_TRS_CHOLESKY): the whole
+// iteration runs on the device from Cholesky factors (newton.hip); an update that meets
+// an indefinite Hessian is redone on the default route.
 //
 // The symmetric eigendecomposition the loop needs (Eigen::SelfAdjointEigenSolver
 // in the reference, src/fmin.hpp:42-44,99-101) is done here by Householder
@@ -185,7 +185,7 @@ using namespace vslam;
 extern "C" vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (solver != VSLAM_TRS_AUTO && solver != VSLAM_TRS_EIG) return fail(ctx, VSLAM_ERR_ARG, "set_trs_solver: unknown solver %d", solver);
+    if (solver != VSLAM_TRS_CHOLESKY && solver != VSLAM_TRS_EIG) return fail(ctx, VSLAM_ERR_ARG, "set_trs_solver: unknown solver %d", solver);
     ctx->trs_solver = solver;
     return VSLAM_OK;
 }
@@ -207,7 +207,7 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool try_device = ctx->trs_solver == VSLAM_TRS_AUTO;
+    const bool try_device = ctx->trs_solver == VSLAM_TRS_CHOLESKY;
     VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n) + (try_device ? newton_ws_bytes(n) : 0)));
     CostDevice c;
     cost_carve(ctx->ws, n, &c);
@@ -223,7 +223,7 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
         VSLAM_TRY(iekf_newton_device(ctx, k, sigma, &c, static_cast<char *>(ctx->ws) + cost_ws_bytes(n), mu_post, S_post, ldSp,
                                      &code, &it, &ev, &status));
         if (status == 0) {
-            ctx->trs_last = VSLAM_TRS_AUTO;
+            ctx->trs_last = VSLAM_TRS_CHOLESKY;
             if (fmin_code) *fmin_code = code;
             if (iters) *iters = it;
             if (cost_evals) *cost_evals = ev;

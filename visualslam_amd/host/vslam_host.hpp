@@ -262,6 +262,10 @@ int measurementUpdateIEKF(const Vec &mux, const Mat &Sxx, const Vec &, const Vec
     return code;
 }
 
+// Opt-in: solve the trust-region subproblems of measurementUpdateIEKF on the device from Cholesky
+// factors instead of the reference's host eigendecomposition (same iterates; see vslam_hip.h).
+inline void useDeviceTrustRegion(bool on) { check(vslam_ctx_set_trs_solver(context(), on ? VSLAM_TRS_CHOLESKY : VSLAM_TRS_EIG)); }
+
 // ---- corner front end ---------------------------------------------------------
 using Feature = vslam_feature;         // {int x; int y; float score;}, src/imagefeatures.h:15-19
 // Keypoints of one 8-bit grayscale frame sorted by score (sortByScore, src/imagefeatures.cpp:20-22).
