@@ -17,6 +17,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   cpu_baseline  the CPU oracle timed on this host (N=1 only), reference-faithful
                 autodiff pass structure, single thread
   corner        the front-end leg: 1080p frames/s with its own roofline
+  dense         (N=1) the 6012 x 6012 square-root QR against the fp64 matrix-core peak and the
+                wall time of one complete 150-landmark measurement update
 """
 import argparse
 import json
@@ -96,6 +98,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step (corner leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-corner", action="store_true")
+    ap.add_argument("--no-dense", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -175,6 +178,11 @@ def main():
         except ImportError:
             corner = None
 
+    dense = None
+    if rank == 0 and world == 1 and not args.no_dense:
+        from bench_dense import run_dense_leg
+        dense = run_dense_leg(ctx, dev, stream)
+
     if rank == 0:
         units = B * L * args.steps * world
         alg = loglik_algorithmic_bytes(n, L) * B
@@ -201,6 +209,8 @@ def main():
         }
         if corner is not None:
             out["corner"] = corner
+        if dense is not None:
+            out["dense"] = dense
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_np, np.tile(ys, (reps, 1))[:B], np.tile(vs, (reps, 1))[:B])
         print(json.dumps(out))
