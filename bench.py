@@ -156,6 +156,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     elapsed = sharding.max_over_ranks(elapsed, device=dev)
+    # results to rank 0 (outside the timed region): the only exchange a sharded batch needs
+    all_vals = sharding.gather_to_root(val)
+    gathered_ok = None if all_vals is None else bool(all(torch.isfinite(v).all().item() for v in all_vals) and len(all_vals) == world)
 
     # single-instance latency of the same update (launch-latency bound; reported, not the headline)
     x1, y1, v1 = x[:1], y[:1], vis[:1]
@@ -204,6 +207,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "loglik_terms_kernel + loglik_assemble_kernel (one point_loglik call)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+            "results_gathered_to_root": gathered_ok,
             "single_instance_latency_us": single_us,
             "single_instance_updates_per_s": L / (single_us * 1e-6),
         }

@@ -57,6 +57,10 @@ def _worker(rank, world, port, total, out):
         got = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(got, pad)
         slowest = sharding.max_over_ranks(0.5 + rank)
+        rooted = sharding.gather_to_root(torch.full((3,), float(rank), dtype=torch.float64))
+        assert (rooted is None) == (rank != 0)
+        if rank == 0:
+            assert [r.tolist() for r in rooted] == [[float(q)] * 3 for q in range(world)]
         dist.barrier()
         if rank == 0:
             flat = torch.cat([g[g >= 0] for g in got])

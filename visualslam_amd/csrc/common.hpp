@@ -8,8 +8,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/vslam_hip.h"
+
+// A device-to-host copy staged in pinned memory, finished (pinned -> caller's buffer) after the stream drains.
+struct vslam_pending_copy { void *dst; const void *src; size_t width, height, dpitch; };
 
 struct vslam_ctx {
     int device = 0;
@@ -19,8 +23,9 @@ struct vslam_ctx {
     size_t ws_bytes = 0;
     void *scratch = nullptr;     // kernel-internal scratch (partial results), separate so that an
     size_t scratch_bytes = 0;    // entry point's carve-up of `ws` stays valid across launches
-    void *pinned = nullptr;      // small pinned host staging buffer
-    size_t pinned_bytes = 0;
+    void *pinned = nullptr;      // pinned host staging arena of the host-pointer entry points
+    size_t pinned_bytes = 0, pinned_off = 0;
+    std::vector<vslam_pending_copy> pending;
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose barrier gave up
@@ -63,6 +68,15 @@ vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes);
 vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes);
 // Synchronises the context's stream and turns a raised device flag into an error.
 vslam_status stream_finish(vslam_ctx *ctx);
+// Synchronises the stream and completes the staged device-to-host copies.
+vslam_status stream_sync(vslam_ctx *ctx);
+// Host <-> device copies of the host-pointer entry points, staged through pinned memory (pageable
+// hipMemcpyAsync runs at a fraction of the PCIe rate).  Pitches and widths in bytes; the host side
+// may be strided.  d2h results are valid after stream_sync / stream_finish.
+vslam_status h2d(vslam_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+vslam_status d2h(vslam_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height);
+vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height);
 // Creates ctx->side and ctx->ev[] on first use.
 vslam_status side_stream_init(vslam_ctx *ctx);
 

@@ -17,7 +17,7 @@
 //   output   response > threshold, inside the border; sorted by score
 //            descending, then y, then x ascending; first max_features.
 //
-// Kernel 1 (corner_tile_kernel): one workgroup per 64x32 output tile.  The u8
+// Kernel 1 (corner_tile_kernel): one workgroup per 64x16 output tile.  The u8
 // tile plus a (block/2+2)-pixel halo is read once from HBM with aligned 4-byte
 // row loads into LDS; gradients -> products -> separable running window sums
 // -> response -> NMS all stay in LDS.  Survivors are staged in LDS and appended
@@ -31,7 +31,7 @@
 
 namespace vslam {
 
-constexpr int TW = 64, TH = 32;            // output tile
+constexpr int TW = 64, TH = 16;            // output tile: 40 KB of LDS, four workgroups per CU (64x32 tiles: two, 25% slower)
 constexpr int MAXHB = 7;                   // block_size <= 15
 constexpr int SORT_S = 16384;              // keys per LDS sort
 constexpr int CAND_CHUNKS = 4;             // candidate capacity = 4 * SORT_S per frame and detector
@@ -79,13 +79,14 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     const int IW = TW + 2 * halo, IH = TH + 2 * halo;      // image tile
     const int GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1);  // gradient-product tile (response ring +-hb)
     const int RW = TW + 2, RH = TH + 2;            // response tile
+    const int IP = IW | 1, GP = GW | 1, RP = RW | 1;   // odd LDS row pitches: rows land in different banks
     // LDS carve-up (int32 everywhere: exact integer structure tensor)
     int32_t *pa = reinterpret_cast<int32_t *>(smem);               // GW*GH   Ix^2   (later: Harris map)
-    int32_t *pb = pa + GW * GH;                                    //         Iy^2   (later: Shi-Tomasi map)
-    int32_t *pc = pb + GW * GH;                                    //         IxIy   (later: staged candidates)
-    int32_t *ha = pc + GW * GH;                                    // RW*GH   horizontal sums
-    int32_t *hbb = ha + RW * GH;
-    int32_t *hc = hbb + RW * GH;
+    int32_t *pb = pa + GP * GH;                                    //         Iy^2   (later: Shi-Tomasi map)
+    int32_t *pc = pb + GP * GH;                                    //         IxIy   (later: staged candidates)
+    int32_t *ha = pc + GP * GH;                                    // RW*GH   horizontal sums
+    int32_t *hbb = ha + RP * GH;
+    int32_t *hc = hbb + RP * GH;
     int32_t *img = ha;                                             // IW*IH unpacked pixels, dead before ha is written
 
     const int tid = threadIdx.x;
@@ -115,26 +116,26 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int lx = gx + b - gx0;
-                if (lx >= 0 && lx < IW) img[r * IW + lx] = (int32_t)((word >> (8 * b)) & 255u);
+                if (lx >= 0 && lx < IW) img[r * IP + lx] = (int32_t)((word >> (8 * b)) & 255u);
             }
         }
     }
     __syncthreads();
     // ---- 2. Sobel gradients and their products, sliding a 3x3 window along x ----
     {
-        const int seglen = (GW + 5) / 6;
-        for (int item = tid; item < GH * 6; item += 256) {
-            const int ly = item / 6, sgm = item - ly * 6;
+        const int nseg = max(1, 256 / GH), seglen = (GW + nseg - 1) / nseg;   // ~one (row, segment) item per thread
+        for (int item = tid; item < GH * nseg; item += 256) {
+            const int ly = item / nseg, sgm = item - ly * nseg;
             const int xb = sgm * seglen, xe = min(GW, xb + seglen);
             if (xb >= xe) continue;
-            const int32_t *r0 = img + ly * IW + xb, *r1 = r0 + IW, *r2 = r1 + IW;
+            const int32_t *r0 = img + ly * IP + xb, *r1 = r0 + IP, *r2 = r1 + IP;
             int a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1], c0 = r2[0], c1 = r2[1];
             for (int lx = xb; lx < xe; ++lx) {
                 const int o = lx - xb + 2;
                 const int a2 = r0[o], b2 = r1[o], c2 = r2[o];
                 const int ix = (a2 - a0) + 2 * (b2 - b0) + (c2 - c0);
                 const int iy = (c0 - a0) + 2 * (c1 - a1) + (c2 - a2);
-                const int p = ly * GW + lx;
+                const int p = ly * GP + lx;
                 pa[p] = ix * ix; pb[p] = iy * iy; pc[p] = ix * iy;
                 a0 = a1; a1 = a2; b0 = b1; b1 = b2; c0 = c1; c1 = c2;
             }
@@ -143,15 +144,15 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     __syncthreads();
     // ---- 3. horizontal window sums (running sums; integers, so exact): RW x GH ----
     {
-        const int seglen = (RW + 5) / 6, bs = a.bs;
-        for (int item = tid; item < GH * 6; item += 256) {
-            const int ly = item / 6, sgm = item - ly * 6;
+        const int nseg = max(1, 256 / GH), seglen = (RW + nseg - 1) / nseg, bs = a.bs;
+        for (int item = tid; item < GH * nseg; item += 256) {
+            const int ly = item / nseg, sgm = item - ly * nseg;
             const int xb = sgm * seglen, xe = min(RW, xb + seglen);
             if (xb >= xe) continue;
-            const int32_t *qa = pa + ly * GW + xb, *qb = pb + ly * GW + xb, *qc = pc + ly * GW + xb;
+            const int32_t *qa = pa + ly * GP + xb, *qb = pb + ly * GP + xb, *qc = pc + ly * GP + xb;
             int sa = 0, sb = 0, sc = 0;
             for (int t = 0; t < bs; ++t) { sa += qa[t]; sb += qb[t]; sc += qc[t]; }
-            int o = ly * RW + xb;
+            int o = ly * RP + xb;
             ha[o] = sa; hbb[o] = sb; hc[o] = sc;
             for (int lx = xb + 1; lx < xe; ++lx) {
                 const int in = lx - xb + bs - 1, out = lx - xb - 1;
@@ -170,18 +171,18 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
             const int sgm = item / RW, lx = item - sgm * RW;
             const int yb = sgm * vlen, ye = min(RH, yb + vlen);
             int sa = 0, sb = 0, sc = 0;
-            for (int t = 0; t < bs; ++t) { const int q = (yb + t) * RW + lx; sa += ha[q]; sb += hbb[q]; sc += hc[q]; }
+            for (int t = 0; t < bs; ++t) { const int q = (yb + t) * RP + lx; sa += ha[q]; sb += hbb[q]; sc += hc[q]; }
             const int gx = x0 - 1 + lx;
             for (int ly = yb; ly < ye; ++ly) {
                 if (ly > yb) {
-                    const int in = (ly + bs - 1) * RW + lx, out = (ly - 1) * RW + lx;
+                    const int in = (ly + bs - 1) * RP + lx, out = (ly - 1) * RP + lx;
                     sa += ha[in] - ha[out]; sb += hbb[in] - hbb[out]; sc += hc[in] - hc[out];
                 }
                 const int gy = y0 - 1 + ly;
                 const bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
                 const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
                 const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
-                const int i = ly * RW + lx;
+                const int i = ly * RP + lx;
                 if (DET & 1) {
                     const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
                     const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
         const int ly = i >> 6, lx = i & 63;
         const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= w || gy >= h) continue;
-        const int c = (ly + 1) * RW + (lx + 1);
+        const int c = (ly + 1) * RP + (lx + 1);
         if (MAPS) {
             if ((DET & 1) && a.map_h) a.map_h[(size_t)gy * w + gx] = resp_h[c];
             if ((DET & 2) && a.map_s) a.map_s[(size_t)gy * w + gx] = resp_s[c];
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
             const float thr = det == 0 ? a.thr_h : a.thr_s;
             const float r = rp[c];
             if (!(r > thr)) continue;
-            const bool ok = r > rp[c - RW - 1] && r > rp[c - RW] && r > rp[c - RW + 1] && r > rp[c - 1] &&
-                            r >= rp[c + 1] && r >= rp[c + RW - 1] && r >= rp[c + RW] && r >= rp[c + RW + 1];
+            const bool ok = r > rp[c - RP - 1] && r > rp[c - RP] && r > rp[c - RP + 1] && r > rp[c - 1] &&
+                            r >= rp[c + 1] && r >= rp[c + RP - 1] && r >= rp[c + RP] && r >= rp[c + RP + 1];
             if (!ok) continue;
             const int slot = atomicAdd(&lcnt[det], 1);
             if (slot < STAGE_CAP) stage[det * STAGE_CAP + slot] = make_key(r, gx, gy);
@@ -331,8 +332,9 @@ static size_t tile_lds_bytes(int bs)
 {
     const int hb = bs / 2, halo = hb + 2;
     const int IW = TW + 2 * halo, IH = TH + 2 * halo, GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1), RW = TW + 2;
-    size_t sums = (size_t)RW * GH * 4 * 3, imgb = (size_t)IW * IH * 4;     // the image tile overlays the sums
-    size_t b = (size_t)GW * GH * 4 * 3 + (sums > imgb ? sums : imgb);
+    const int IP = IW | 1, GP = GW | 1, RP = RW | 1;                       // odd row pitches, as in the kernel
+    size_t sums = (size_t)RP * GH * 4 * 3, imgb = (size_t)IP * IH * 4;     // the image tile overlays the sums
+    size_t b = (size_t)GP * GH * 4 * 3 + (sums > imgb ? sums : imgb);
     return (b + 15) & ~size_t(15);
 }
 
@@ -446,12 +448,12 @@ extern "C" vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray,
     vslam_feature *dout = ar.take<vslam_feature>((size_t)ndet * cap);
     int32_t *dcount = ar.take<int32_t>(2);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dimg, gray, img_bytes, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dimg, gray, img_bytes));
     CornerArgs a = make_args(dimg, w, h, stride, 0, params);
     VSLAM_TRY(launch_detect(ctx, a, 1, detector, params, dout, cap, dcount, dws));
     int32_t hc[2] = {0, 0};
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(hc, dcount, ndet * 4, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    VSLAM_TRY(d2h(ctx, hc, dcount, ndet * 4));
+    VSLAM_TRY(stream_sync(ctx));
     for (int d = 0; d < ndet; ++d) {
         if (hc[d] < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "corner_detect: more than %d candidates survive NMS; raise the threshold", CAND_CAP);
         count[d] = hc[d];
@@ -475,15 +477,15 @@ extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gra
     uint8_t *dimg = ar.take<uint8_t>(img_bytes);
     float *dh = ar.take<float>((size_t)w * h), *ds = ar.take<float>((size_t)w * h);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dimg, gray, img_bytes, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dimg, gray, img_bytes));
     CornerArgs a = make_args(dimg, w, h, stride, 0, params);
     a.map_h = dh; a.map_s = ds;
     a.tiles_x = (w + TW - 1) / TW; a.frames = 1;
     dim3 grid((unsigned)(a.tiles_x * ((h + TH - 1) / TH)));
     hipLaunchKernelGGL((corner_tile_kernel<3, true>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    if (harris) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(harris, dh, map_bytes, hipMemcpyDeviceToHost, s));
-    if (shi) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(shi, ds, map_bytes, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (harris) VSLAM_TRY(d2h(ctx, harris, dh, map_bytes));
+    if (shi) VSLAM_TRY(d2h(ctx, shi, ds, map_bytes));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }

@@ -44,6 +44,66 @@ vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes)
     return VSLAM_OK;
 }
 
+static vslam_status pinned_take(vslam_ctx *ctx, size_t bytes, char **out)
+{
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->pinned_off + need > ctx->pinned_bytes) {
+        VSLAM_TRY(stream_sync(ctx));                     // everything staged so far is consumed; arena is empty again
+        if (need > ctx->pinned_bytes) {
+            if (ctx->pinned) { VSLAM_HIP_TRY(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+            size_t want = need + (need >> 2);
+            if (want < (size_t(4) << 20)) want = size_t(4) << 20;
+            hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+            if (e != hipSuccess) return fail(ctx, VSLAM_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            ctx->pinned_bytes = want;
+        }
+    }
+    *out = static_cast<char *>(ctx->pinned) + ctx->pinned_off;
+    ctx->pinned_off += need;
+    return VSLAM_OK;
+}
+
+vslam_status stream_sync(vslam_ctx *ctx)
+{
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (const vslam_pending_copy &c : ctx->pending) {
+        const char *src = static_cast<const char *>(c.src);
+        char *dst = static_cast<char *>(c.dst);
+        if (c.dpitch == c.width || c.height == 1) std::memcpy(dst, src, c.width * c.height);
+        else for (size_t r = 0; r < c.height; ++r) std::memcpy(dst + r * c.dpitch, src + r * c.width, c.width);
+    }
+    ctx->pending.clear();
+    ctx->pinned_off = 0;
+    return VSLAM_OK;
+}
+
+vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height)
+{
+    if (width == 0 || height == 0) return VSLAM_OK;
+    char *stage;
+    VSLAM_TRY(pinned_take(ctx, width * height, &stage));
+    const char *src = static_cast<const char *>(src_host);
+    if (spitch == width || height == 1) std::memcpy(stage, src, width * height);
+    else for (size_t r = 0; r < height; ++r) std::memcpy(stage + r * width, src + r * spitch, width);
+    if (dpitch == width || height == 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, stage, width * height, hipMemcpyHostToDevice, ctx->stream));
+    else VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dst_dev, dpitch, stage, width, width, height, hipMemcpyHostToDevice, ctx->stream));
+    return VSLAM_OK;
+}
+
+vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height)
+{
+    if (width == 0 || height == 0) return VSLAM_OK;
+    char *stage;
+    VSLAM_TRY(pinned_take(ctx, width * height, &stage));
+    if (spitch == width || height == 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(stage, src_dev, width * height, hipMemcpyDeviceToHost, ctx->stream));
+    else VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(stage, width, src_dev, spitch, width, height, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending.push_back({dst_host, stage, width, height, dpitch});
+    return VSLAM_OK;
+}
+
+vslam_status h2d(vslam_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) { return h2d_2d(ctx, dst_dev, bytes, src_host, bytes, bytes, 1); }
+vslam_status d2h(vslam_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) { return d2h_2d(ctx, dst_host, bytes, src_dev, bytes, bytes, 1); }
+
 vslam_status side_stream_init(vslam_ctx *ctx)
 {
     if (ctx->side) return VSLAM_OK;
@@ -56,7 +116,7 @@ vslam_status side_stream_init(vslam_ctx *ctx)
 vslam_status stream_finish(vslam_ctx *ctx)
 {
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(ctx->flags_host, ctx->flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    VSLAM_TRY(stream_sync(ctx));
     if (ctx->flags_host[0] != 0) {
         ctx->flags_host[0] = 0;
         VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->flags, 0, sizeof(int), ctx->stream));

@@ -210,13 +210,13 @@ extern "C" vslam_status vslam_log_gaussian(vslam_ctx *ctx, const double *x, cons
     double *dH = H ? ar.take<double>(nn) : nullptr, *dW = H ? ar.take<double>(nn) : nullptr;
     void *tws = H ? ar.take<char>(trtri_ws_bytes(n)) : nullptr;
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dmu, mu, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, x, n * 8));
+    VSLAM_TRY(h2d(ctx, dmu, mu, n * 8));
+    VSLAM_TRY(h2d_2d(ctx, dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
     VSLAM_TRY(log_gaussian_dev(ctx, dx, dmu, dS, n, n, dval, (g || H) ? dg : nullptr, dH, dtmp, dW, tws));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(value, dval, 8, hipMemcpyDeviceToHost, s));
-    if (g) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g, dg, n * 8, hipMemcpyDeviceToHost, s));
-    if (H) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H, dH, nn * 8, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, value, dval, 8));
+    if (g) VSLAM_TRY(d2h(ctx, g, dg, n * 8));
+    if (H) VSLAM_TRY(d2h(ctx, H, dH, nn * 8));
     return stream_finish(ctx);
 }
 
@@ -234,15 +234,15 @@ extern "C" vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n
     double *dS = ar.take<double>((size_t)n * n), *dC = ar.take<double>((size_t)m * n), *dA = ar.take<double>((size_t)rows * m);
     void *qws = ar.take<char>(qr_ws_bytes(rows, m, 1));
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dC, (size_t)m * 8, C, (size_t)ldC * 8, (size_t)m * 8, n, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dA + n, (size_t)rows * 8, SR, (size_t)ldSR * 8, (size_t)m * 8, m, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d_2d(ctx, dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
+    VSLAM_TRY(h2d_2d(ctx, dC, (size_t)m * 8, C, (size_t)ldC * 8, (size_t)m * 8, n));
+    VSLAM_TRY(h2d_2d(ctx, dA + n, (size_t)rows * 8, SR, (size_t)ldSR * 8, (size_t)m * 8, m));
     GemmDesc d;                                          // top block: S * C^T   (src/gaussian.hpp:119)
     d.M = n; d.N = m; d.K = n; d.transA = false; d.transB = true;
     d.A = dS; d.lda = n; d.B = dC; d.ldb = m; d.C = dA; d.ldc = rows;
     VSLAM_TRY(gemm_f64(ctx, d));
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, 0, 1, qws));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h_2d(ctx, Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m));
     return stream_finish(ctx);
 }
 
@@ -268,15 +268,15 @@ extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *
     double *dA = ar.take<double>((size_t)rows * m);
     void *qws = ar.take<char>(qr_ws_bytes(rows, m, 1));
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, mux, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dS, (size_t)n * 8, Sxx, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, mux, n * 8));
+    VSLAM_TRY(h2d_2d(ctx, dS, (size_t)n * 8, Sxx, (size_t)ldS * 8, (size_t)n * 8, n));
     hipLaunchKernelGGL(bundle_jac_compact_kernel, dim3((L + 63) / 64), dim3(64), 0, s, k, dx, L, layout, dh, dc, rec);
     hipLaunchKernelGGL(s_times_ct_kernel, dim3((rows + 255) / 256, L), dim3(256), 0, s, dS, n, n, rec, L, layout, dA, rows);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, 0, 1, qws));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(muy, dh, m * 8, hipMemcpyDeviceToHost, s));
-    if (code) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, L * 4, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, muy, dh, m * 8));
+    if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));
+    VSLAM_TRY(d2h_2d(ctx, Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m));
     return stream_finish(ctx);
 }
 
@@ -292,12 +292,12 @@ extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, co
     double *dQ = ar.take<double>(nn), *dA = ar.take<double>(nn), *dv = ar.take<double>(n);
     void *qws = ar.take<char>(qr_ws_bytes(n, n, 1));
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dQ, Q, nn * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dv, v, n * 8, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dQ, Q, nn * 8));
+    VSLAM_TRY(h2d(ctx, dv, v, n * 8));
     hipLaunchKernelGGL(scaled_transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, dQ, dv, n, dA);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     VSLAM_TRY(qr_upper_dev(ctx, dA, n, n, n, 0, 1, qws));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(S_out, dA, nn * 8, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, S_out, dA, nn * 8));
     return stream_finish(ctx);
 }
 
@@ -314,16 +314,16 @@ extern "C" vslam_status vslam_condition_on_marginal(vslam_ctx *ctx, const double
     double *dS = ar.take<double>((size_t)nt * nt), *dmu = ar.take<double>(nt), *dy = ar.take<double>(nt), *dt = ar.take<double>(nt),
            *dout = ar.take<double>(nt), *dSx = ar.take<double>((size_t)nx * nx);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dS, (size_t)nt * 8, Syx, (size_t)ld * 8, (size_t)nt * 8, nt, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dmu, muyx, nt * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dy, y, ny * 8, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d_2d(ctx, dS, (size_t)nt * 8, Syx, (size_t)ld * 8, (size_t)nt * 8, nt));
+    VSLAM_TRY(h2d(ctx, dmu, muyx, nt * 8));
+    VSLAM_TRY(h2d(ctx, dy, y, ny * 8));
     hipLaunchKernelGGL(vec_sub_kernel, dim3((ny + 255) / 256), dim3(256), 0, s, dy, dmu, dt, ny);
     VSLAM_TRY(trsv_upper_dev(ctx, dS, ny, nt, true, dt, dt));
     hipLaunchKernelGGL(condition_mean_kernel, dim3((nx + 63) / 64), dim3(64), 0, s, dmu, dS, ny, nx, nt, dt, dout);
     hipLaunchKernelGGL(copy2d_kernel, dim3((nx + 255) / 256, nx), dim3(256), 0, s, dS + (size_t)ny * nt + ny, nt, dSx, nx, nx, nx);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mux_out, dout, nx * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(Sx_out, (size_t)ldo * 8, dSx, (size_t)nx * 8, (size_t)nx * 8, nx, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, mux_out, dout, nx * 8));
+    VSLAM_TRY(d2h_2d(ctx, Sx_out, (size_t)ldo * 8, dSx, (size_t)nx * 8, (size_t)nx * 8, nx));
     return stream_finish(ctx);
 }
 
@@ -392,14 +392,14 @@ extern "C" vslam_status vslam_cost_joint_density(vslam_ctx *ctx, const vslam_cam
     cost_carve(ctx->ws, n, &c);
     hipStream_t s = ctx->stream;
     const size_t nn = (size_t)n * n;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.x, x, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.mu, mu, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.y, y, 2 * c.L * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.vis, visible, c.L, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, c.x, x, n * 8));
+    VSLAM_TRY(h2d(ctx, c.mu, mu, n * 8));
+    VSLAM_TRY(h2d_2d(ctx, c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
+    VSLAM_TRY(h2d(ctx, c.y, y, 2 * c.L * 8));
+    VSLAM_TRY(h2d(ctx, c.vis, visible, c.L));
     VSLAM_TRY(cost_eval_dev(ctx, k, sigma, &c));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(value, c.vals + 2, 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g, c.g, n * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H, c.H, nn * 8, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, value, c.vals + 2, 8));
+    VSLAM_TRY(d2h(ctx, g, c.g, n * 8));
+    VSLAM_TRY(d2h(ctx, H, c.H, nn * 8));
     return stream_finish(ctx);
 }

@@ -213,10 +213,10 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     cost_carve(ctx->ws, n, &c);
     hipStream_t s = ctx->stream;
     const size_t nn = (size_t)n * n;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.mu, mu, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.y, y, 2 * c.L * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.vis, visible, c.L, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, c.mu, mu, n * 8));
+    VSLAM_TRY(h2d_2d(ctx, c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
+    VSLAM_TRY(h2d(ctx, c.y, y, 2 * c.L * 8));
+    VSLAM_TRY(h2d(ctx, c.vis, visible, c.L));
 
     if (try_device) {
         int code = 1, it = 0, ev = 0, status = 0;
@@ -235,12 +235,12 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     ctx->trs_last = VSLAM_TRS_EIG;
     int evals = 0;
     auto cost = [&](const std::vector<double> &x, std::vector<double> &g, std::vector<double> &H, double *f) -> vslam_status {
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c.x, x.data(), n * 8, hipMemcpyHostToDevice, s));
+        VSLAM_TRY(h2d(ctx, c.x, x.data(), n * 8));
         VSLAM_TRY(cost_eval_dev(ctx, k, sigma, &c));
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(f, c.vals + 2, 8, hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g.data(), c.g, n * 8, hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(H.data(), c.H, nn * 8, hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        VSLAM_TRY(d2h(ctx, f, c.vals + 2, 8));
+        VSLAM_TRY(d2h(ctx, g.data(), c.g, n * 8));
+        VSLAM_TRY(d2h(ctx, H.data(), c.H, nn * 8));
+        VSLAM_TRY(stream_sync(ctx));
         ++evals;
         return VSLAM_OK;
     };

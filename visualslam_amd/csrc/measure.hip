@@ -217,12 +217,12 @@ extern "C" vslam_status vslam_project(vslam_ctx *ctx, const vslam_camera *cam, c
     double *dx = ar.take<double>(n), *dpx = ar.take<double>(2 * L);
     int32_t *dc = ar.take<int32_t>(L);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     hipLaunchKernelGGL(project_kernel, dim3((L + 63) / 64), dim3(64), 0, s, k, dx, j0, L, dpx, dc);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(px, dpx, 2 * L * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, L * 4, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    VSLAM_TRY(d2h(ctx, px, dpx, 2 * L * 8));
+    VSLAM_TRY(d2h(ctx, code, dc, L * 4));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }
 
@@ -245,13 +245,13 @@ extern "C" vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera 
     double *dC = C ? ar.take<double>((size_t)m * n) : nullptr;
     double *dSR = SR ? ar.take<double>((size_t)m * m) : nullptr;
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     VSLAM_TRY(launch_bundle_measure(ctx, k, dx, n, layout, dh, dSR, dC, dc));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(h, dh, m * 8, hipMemcpyDeviceToHost, s));
-    if (code) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, L * 4, hipMemcpyDeviceToHost, s));
-    if (C) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost, s));
-    if (SR) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(SR, dSR, (size_t)m * m * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    VSLAM_TRY(d2h(ctx, h, dh, m * 8));
+    if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));
+    if (C) VSLAM_TRY(d2h(ctx, C, dC, (size_t)m * n * 8));
+    if (SR) VSLAM_TRY(d2h(ctx, SR, dSR, (size_t)m * m * 8));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }
 
@@ -271,14 +271,14 @@ extern "C" vslam_status vslam_single_measure(vslam_ctx *ctx, const vslam_camera 
     double *dx = ar.take<double>(n), *dJ = ar.take<double>(2 * n), *dh = ar.take<double>(2), *dSR = ar.take<double>(4);
     int32_t *dc = ar.take<int32_t>(1);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     hipLaunchKernelGGL(single_measure_kernel, dim3(1), dim3(kThreads), 0, s, k, dx, n, j, layout, dh, SR ? dSR : nullptr,
                        J ? dJ : nullptr, dc);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(h, dh, 16, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, 4, hipMemcpyDeviceToHost, s));
-    if (SR) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(SR, dSR, 32, hipMemcpyDeviceToHost, s));
-    if (J) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(J, dJ, 2 * n * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    VSLAM_TRY(d2h(ctx, h, dh, 16));
+    VSLAM_TRY(d2h(ctx, code, dc, 4));
+    if (SR) VSLAM_TRY(d2h(ctx, SR, dSR, 32));
+    if (J) VSLAM_TRY(d2h(ctx, J, dJ, 2 * n * 8));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }

@@ -218,9 +218,9 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = nullptr; d.b[3] = nullptr;
         hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(hd, w.dots, 4 * 8, hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(&hinfo, w.info, sizeof(int), hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        VSLAM_TRY(d2h(ctx, hd, w.dots, 4 * 8));
+        VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
+        VSLAM_TRY(stream_sync(ctx));
         return VSLAM_OK;
     };
     // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
@@ -237,8 +237,8 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     auto eval_at = [&](const double *x, double *f) -> vslam_status {
         if (x != c->x) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c->x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
         VSLAM_TRY(cost_eval_dev(ctx, k, sigma, c));
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(f, c->vals + 2, 8, hipMemcpyDeviceToHost, s));
-        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+        VSLAM_TRY(d2h(ctx, f, c->vals + 2, 8));
+        VSLAM_TRY(stream_sync(ctx));
         ++evals;
         return VSLAM_OK;
     };
@@ -297,9 +297,9 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, c->Hl, n, c->W);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     VSLAM_TRY(qr_upper_dev(ctx, c->W, n, n, n, 0, 1, w.qws));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(&hinfo, w.info, sizeof(int), hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mu_post, w.xcur, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
+    VSLAM_TRY(d2h(ctx, mu_post, w.xcur, (size_t)n * 8));
+    VSLAM_TRY(d2h_2d(ctx, S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n));
     VSLAM_TRY(stream_finish(ctx));
     if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
     *fmin_code = ret; *iters = it; *evals_out = evals;

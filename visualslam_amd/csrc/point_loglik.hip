@@ -470,14 +470,14 @@ extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *c
     double *dval = ar.take<double>(1);
     double *dH = H ? ar.take<double>(nn) : nullptr;
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dy, y, 2 * L * 8, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dv, visible, L, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dx, x, n * 8));
+    VSLAM_TRY(h2d(ctx, dy, y, 2 * L * 8));
+    VSLAM_TRY(h2d(ctx, dv, visible, L));
     VSLAM_TRY(launch_point_loglik(ctx, k, 1, n, dx, 0, dy, 0, dv, 0, sigma, dval, g ? dg : (H ? dg : nullptr), 0, dH, n, 0, dc));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(value, dval, 8, hipMemcpyDeviceToHost, s));
-    if (g) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(g, dg, n * 8, hipMemcpyDeviceToHost, s));
-    if (code) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(code, dc, L * 4, hipMemcpyDeviceToHost, s));
-    if (H) VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(H, (size_t)ldH * 8, dH, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    VSLAM_TRY(d2h(ctx, value, dval, 8));
+    if (g) VSLAM_TRY(d2h(ctx, g, dg, n * 8));
+    if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));
+    if (H) VSLAM_TRY(d2h_2d(ctx, H, (size_t)ldH * 8, dH, (size_t)n * 8, (size_t)n * 8, n));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }

@@ -776,9 +776,9 @@ extern "C" vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int 
     double *dA = ar.take<double>((size_t)rows * cols);
     void *qws = ar.take<char>(qr_ws_bytes(rows, cols, 1));
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dA, (size_t)rows * 8, A, (size_t)lda * 8, (size_t)rows * 8, cols, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d_2d(ctx, dA, (size_t)rows * 8, A, (size_t)lda * 8, (size_t)rows * 8, cols));
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, cols, rows, 0, 1, qws));
-    VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(A, (size_t)lda * 8, dA, (size_t)rows * 8, (size_t)rows * 8, cols, hipMemcpyDeviceToHost, s));
+    VSLAM_TRY(d2h_2d(ctx, A, (size_t)lda * 8, dA, (size_t)rows * 8, (size_t)rows * 8, cols));
     return stream_finish(ctx);
 }
 
@@ -796,16 +796,16 @@ extern "C" vslam_status vslam_debug_gemm(vslam_ctx *ctx, int M, int N, int K, in
     double *dA = ar.take<double>((size_t)lda * colsA), *dB = ar.take<double>((size_t)ldb * colsB), *dC = ar.take<double>((size_t)ldc * N);
     double *dS = ar.take<double>((size_t)ldc * N * ks);
     hipStream_t s = ctx->stream;
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dA, A, ba, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dB, B, bb, hipMemcpyHostToDevice, s));
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dC, C, bc, hipMemcpyHostToDevice, s));
+    VSLAM_TRY(h2d(ctx, dA, A, ba));
+    VSLAM_TRY(h2d(ctx, dB, B, bb));
+    VSLAM_TRY(h2d(ctx, dC, C, bc));
     GemmDesc g;
     g.M = M; g.N = N; g.K = K; g.transA = transA != 0; g.transB = transB != 0; g.amode = (AMode)amode; g.b_upper = b_upper != 0;
     g.alpha = alpha; g.beta = beta; g.A = dA; g.lda = lda; g.B = dB; g.ldb = ldb; g.C = dC; g.ldc = ldc;
     if (ks > 1) { g.C = dS; g.ksplit = ks; g.strideSplit = (size_t)ldc * N; }
     VSLAM_TRY(gemm_f64(ctx, g));
-    if (ks > 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(C, dS, bc * ks, hipMemcpyDeviceToHost, s));   // caller sums the slabs
-    else VSLAM_HIP_TRY(ctx, hipMemcpyAsync(C, dC, bc, hipMemcpyDeviceToHost, s));
-    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (ks > 1) VSLAM_TRY(d2h(ctx, C, dS, bc * ks));   // caller sums the slabs
+    else VSLAM_TRY(d2h(ctx, C, dC, bc));
+    VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
 }

@@ -51,3 +51,19 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_to_root(tensor, device=None):
+    """Results of all ranks on rank 0 (list indexed by rank; None on the other ranks): the one exchange
+    a sharded batch needs, after the compute.  Every rank passes a tensor of the same shape and dtype."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [tensor]
+    t = tensor if device is None else tensor.to(device)
+    if dist.get_rank() == 0:
+        out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.gather(t, gather_list=out, dst=0)
+        return out
+    dist.gather(t, gather_list=None, dst=0)
+    return None
