@@ -69,12 +69,15 @@ struct CornerArgs {
 // grid.x = tiles * frames with the frame index fastest, so the workgroups in
 // flight at any moment belong to many frames and their (one per workgroup and
 // detector) candidate-count atomics spread over many counters.
-template <int DET, bool MAPS>
+// BS: window size fixed at compile time (7, cv::ORB's Harris block) so that every thread's LDS reads of a stage are
+// issued together and the short loops are unrolled; BS = 0 takes the window size from the arguments.
+template <int DET, bool MAPS, int BS>
 __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int lcnt[2], gbase[2];
-    const int hb = a.bs >> 1, R = hb + 1;          // response needs image +-R
+    const int wbs = BS > 0 ? BS : a.bs;
+    const int hb = wbs >> 1, R = hb + 1;           // response needs image +-R
     const int halo = R + 1;                        // +1 for the NMS ring
     const int IW = TW + 2 * halo, IH = TH + 2 * halo;      // image tile
     const int GW = TW + 2 * (hb + 1), GH = TH + 2 * (hb + 1);  // gradient-product tile (response ring +-hb)
@@ -103,26 +106,55 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
         const int ax0 = gx0 & ~3;
         const int ND = ((gx0 + IW - 1) >> 2) - (ax0 >> 2) + 1;
         const bool fast_ok = ((a.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
-        for (int item = tid; item < ND * IH; item += 256) {
-            const int r = item / ND, d = item - r * ND;
-            const int gy = gy0 + r, gx = ax0 + 4 * d;
-            const int cy = min(max(gy, 0), h - 1);
-            uint32_t word;
-            if (fast_ok && gx >= 0 && gx + 3 < w) word = *reinterpret_cast<const uint32_t *>(gray + (size_t)cy * a.stride + gx);
-            else {
-                word = 0;
-                for (int b = 0; b < 4; ++b) word |= (uint32_t)gray[(size_t)cy * a.stride + min(max(gx + b, 0), w - 1)] << (8 * b);
-            }
+        // every thread's row words are requested before any is unpacked (at most MAXIT rounds of 256 items)
+        constexpr int MAXIT = ((TW + 2 * (MAXHB + 2) + 6) / 4 + 1) * (TH + 2 * (MAXHB + 2)) / 256 + 1;
+        uint32_t words[MAXIT];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int lx = gx + b - gx0;
-                if (lx >= 0 && lx < IW) img[r * IP + lx] = (int32_t)((word >> (8 * b)) & 255u);
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = tid + it * 256;
+            words[it] = 0;
+            if (item < ND * IH) {
+                const int r = item / ND, d = item - r * ND;
+                const int gy = gy0 + r, gx = ax0 + 4 * d;
+                const int cy = min(max(gy, 0), h - 1);
+                if (fast_ok && gx >= 0 && gx + 3 < w) words[it] = *reinterpret_cast<const uint32_t *>(gray + (size_t)cy * a.stride + gx);
+                else
+                    for (int b = 0; b < 4; ++b) words[it] |= (uint32_t)gray[(size_t)cy * a.stride + min(max(gx + b, 0), w - 1)] << (8 * b);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = tid + it * 256;
+            if (item < ND * IH) {
+                const int r = item / ND, d = item - r * ND;
+                const int gx = ax0 + 4 * d;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int lx = gx + b - gx0;
+                    if (lx >= 0 && lx < IW) img[r * IP + lx] = (int32_t)((words[it] >> (8 * b)) & 255u);
+                }
             }
         }
     }
     __syncthreads();
-    // ---- 2. Sobel gradients and their products, sliding a 3x3 window along x ----
-    {
+    // ---- 2. Sobel gradients and their products ----
+    if (BS == 7) {
+        constexpr int NSEG = 9, SEG = 8;           // GW = 72 = 9 segments of 8 columns
+        for (int item = tid; item < GH * NSEG; item += 256) {
+            const int ly = item / NSEG, xb = (item - ly * NSEG) * SEG;
+            const int32_t *r0 = img + ly * IP + xb;
+            int v0[SEG + 2], v1[SEG + 2], v2[SEG + 2];
+#pragma unroll
+            for (int k = 0; k < SEG + 2; ++k) { v0[k] = r0[k]; v1[k] = r0[IP + k]; v2[k] = r0[2 * IP + k]; }
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) {
+                const int ix = (v0[k + 2] - v0[k]) + 2 * (v1[k + 2] - v1[k]) + (v2[k + 2] - v2[k]);
+                const int iy = (v2[k] - v0[k]) + 2 * (v2[k + 1] - v0[k + 1]) + (v2[k + 2] - v0[k + 2]);
+                const int p = ly * GP + xb + k;
+                pa[p] = ix * ix; pb[p] = iy * iy; pc[p] = ix * iy;
+            }
+        }
+    } else {
         const int nseg = max(1, 256 / GH), seglen = (GW + nseg - 1) / nseg;   // ~one (row, segment) item per thread
         for (int item = tid; item < GH * nseg; item += 256) {
             const int ly = item / nseg, sgm = item - ly * nseg;
@@ -143,7 +175,27 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     }
     __syncthreads();
     // ---- 3. horizontal window sums (running sums; integers, so exact): RW x GH ----
-    {
+    if (BS == 7) {
+        constexpr int NSEG = 9, SEG = 8;           // RW = 66 <= 72
+        for (int item = tid; item < GH * NSEG; item += 256) {
+            const int ly = item / NSEG, xb = (item - ly * NSEG) * SEG;
+            const int32_t *qa = pa + ly * GP, *qb = pb + ly * GP, *qc = pc + ly * GP;
+            int va[SEG + 6], vb[SEG + 6], vc[SEG + 6];
+#pragma unroll
+            for (int k = 0; k < SEG + 6; ++k) {
+                const int x = min(xb + k, GW - 1);
+                va[k] = qa[x]; vb[k] = qb[x]; vc[k] = qc[x];
+            }
+            int sa = 0, sb = 0, sc = 0;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) { sa += va[t]; sb += vb[t]; sc += vc[t]; }
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) {
+                if (k > 0) { sa += va[k + 6] - va[k - 1]; sb += vb[k + 6] - vb[k - 1]; sc += vc[k + 6] - vc[k - 1]; }
+                if (xb + k < RW) { const int o = ly * RP + xb + k; ha[o] = sa; hbb[o] = sb; hc[o] = sc; }
+            }
+        }
+    } else {
         const int nseg = max(1, 256 / GH), seglen = (RW + nseg - 1) / nseg, bs = a.bs;
         for (int item = tid; item < GH * nseg; item += 256) {
             const int ly = item / nseg, sgm = item - ly * nseg;
@@ -166,17 +218,35 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     // ---- 4. vertical running sums + response: RW x RH, stored over the product buffers ----
     float *resp_h = reinterpret_cast<float *>(pa), *resp_s = reinterpret_cast<float *>(pb);
     {
-        const int vlen = (RH + 2) / 3, bs = a.bs;
+        const int vlen = (RH + 2) / 3, bs = wbs;
         for (int item = tid; item < RW * 3; item += 256) {
             const int sgm = item / RW, lx = item - sgm * RW;
             const int yb = sgm * vlen, ye = min(RH, yb + vlen);
+            constexpr int VROWS = (TH + 2 + 2) / 3 + 6;            // rows one thread reads when BS == 7
+            int ca[VROWS], cb[VROWS], cc[VROWS];
             int sa = 0, sb = 0, sc = 0;
-            for (int t = 0; t < bs; ++t) { const int q = (yb + t) * RP + lx; sa += ha[q]; sb += hbb[q]; sc += hc[q]; }
+            if (BS == 7) {
+#pragma unroll
+                for (int t = 0; t < VROWS; ++t) {
+                    const int q = min(yb + t, GH - 1) * RP + lx;
+                    ca[t] = ha[q]; cb[t] = hbb[q]; cc[t] = hc[q];
+                }
+#pragma unroll
+                for (int t = 0; t < 7; ++t) { sa += ca[t]; sb += cb[t]; sc += cc[t]; }
+            } else {
+                for (int t = 0; t < bs; ++t) { const int q = (yb + t) * RP + lx; sa += ha[q]; sb += hbb[q]; sc += hc[q]; }
+            }
             const int gx = x0 - 1 + lx;
-            for (int ly = yb; ly < ye; ++ly) {
-                if (ly > yb) {
-                    const int in = (ly + bs - 1) * RP + lx, out = (ly - 1) * RP + lx;
-                    sa += ha[in] - ha[out]; sb += hbb[in] - hbb[out]; sc += hc[in] - hc[out];
+#pragma unroll 8
+            for (int j = 0; j < (BS == 7 ? VROWS - 6 : 1 << 20); ++j) {
+                const int ly = yb + j;
+                if (ly >= ye) break;
+                if (j > 0) {
+                    if (BS == 7) { sa += ca[j + 6] - ca[j - 1]; sb += cb[j + 6] - cb[j - 1]; sc += cc[j + 6] - cc[j - 1]; }
+                    else {
+                        const int in = (ly + bs - 1) * RP + lx, out = (ly - 1) * RP + lx;
+                        sa += ha[in] - ha[out]; sb += hbb[in] - hbb[out]; sc += hc[in] - hc[out];
+                    }
                 }
                 const int gy = y0 - 1 + ly;
                 const bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
@@ -379,9 +449,15 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     dim3 grid((unsigned)((size_t)a.tiles_x * ((a.h + TH - 1) / TH) * frames));
     size_t lds = tile_lds_bytes(a.bs);
     const int det_mask = detector == 2 ? 3 : (1 << detector);
-    if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false>), grid, dim3(256), lds, s, a);
-    else if (det_mask == 2) hipLaunchKernelGGL((corner_tile_kernel<2, false>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((corner_tile_kernel<3, false>), grid, dim3(256), lds, s, a);
+    if (a.bs == 7) {
+        if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false, 7>), grid, dim3(256), lds, s, a);
+        else if (det_mask == 2) hipLaunchKernelGGL((corner_tile_kernel<2, false, 7>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((corner_tile_kernel<3, false, 7>), grid, dim3(256), lds, s, a);
+    } else {
+        if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false, 0>), grid, dim3(256), lds, s, a);
+        else if (det_mask == 2) hipLaunchKernelGGL((corner_tile_kernel<2, false, 0>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((corner_tile_kernel<3, false, 0>), grid, dim3(256), lds, s, a);
+    }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, det_mask);
     for (int step = 1; step < CAND_CHUNKS; step <<= 1)
@@ -403,10 +479,12 @@ static vslam_status ensure_lds_attr(vslam_ctx *ctx)
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     const int big = (int)tile_lds_bytes(2 * MAXHB + 1);
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&corner_tile_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    const void *tile_kernels[] = {
+        reinterpret_cast<const void *>(&corner_tile_kernel<1, false, 0>), reinterpret_cast<const void *>(&corner_tile_kernel<2, false, 0>),
+        reinterpret_cast<const void *>(&corner_tile_kernel<3, false, 0>), reinterpret_cast<const void *>(&corner_tile_kernel<3, true, 0>),
+        reinterpret_cast<const void *>(&corner_tile_kernel<1, false, 7>), reinterpret_cast<const void *>(&corner_tile_kernel<2, false, 7>),
+        reinterpret_cast<const void *>(&corner_tile_kernel<3, false, 7>), reinterpret_cast<const void *>(&corner_tile_kernel<3, true, 7>)};
+    for (const void *kfn : tile_kernels) VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     done = true;
     return VSLAM_OK;
 }
@@ -482,7 +560,8 @@ extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gra
     a.map_h = dh; a.map_s = ds;
     a.tiles_x = (w + TW - 1) / TW; a.frames = 1;
     dim3 grid((unsigned)(a.tiles_x * ((h + TH - 1) / TH)));
-    hipLaunchKernelGGL((corner_tile_kernel<3, true>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
+    if (a.bs == 7) hipLaunchKernelGGL((corner_tile_kernel<3, true, 7>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
+    else hipLaunchKernelGGL((corner_tile_kernel<3, true, 0>), grid, dim3(256), tile_lds_bytes(a.bs), s, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     if (harris) VSLAM_TRY(d2h(ctx, harris, dh, map_bytes));
     if (shi) VSLAM_TRY(d2h(ctx, shi, ds, map_bytes));
