@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 databases collected by tools/profile_on_gpu.sh (gpurun_out/prof/) into the
+small summaries committed under profiles/:  python tools/condense_profiles.py r01"""
+import csv
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def kernel_stats(db_path, csv_path):
+    db = sqlite3.connect(db_path)
+    rows = list(db.execute("select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
+                           "from kernels group by name order by sum(end - start) desc"))
+    total = sum(r[2] for r in rows) or 1
+    with open(csv_path, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for name, calls, tot, avg, mn, mx in rows:
+            w.writerow([name, calls, tot, "%.1f" % avg, "%.2f" % (100.0 * tot / total), mn, mx])
+    return {r[0]: {"calls": r[1], "avg_ns": r[3]} for r in rows}
+
+
+def counters(db_path, names):
+    db = sqlite3.connect(db_path)
+    out = {}
+    for kname, cname, mean, cnt in db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                              "group by kernel_name, counter_name"):
+        if any(k in kname for k in names):
+            out.setdefault(kname, {})[cname] = mean
+            out[kname]["launches"] = cnt
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(DST, exist_ok=True)
+    stats = kernel_stats(os.path.join(SRC, "bench", "bench_results.db"), os.path.join(DST, tag + "_bench_kernel_stats.csv"))
+    kernel_stats(os.path.join(SRC, "qr", "qr_results.db"), os.path.join(DST, tag + "_qr6012_kernel_stats.csv"))
+    with open(os.path.join(SRC, "bench.log")) as f:
+        line = [l for l in f if l.startswith("{")][-1]
+    with open(os.path.join(DST, tag + "_bench.json"), "w") as f:
+        f.write(line)
+
+    fetch = counters(os.path.join(SRC, "fetch", "fetch_results.db"), ["loglik"])
+    write = counters(os.path.join(SRC, "write", "write_results.db"), ["loglik"])
+    B, L, n = 512, 150, 462
+    alg = (8 * n * n + 16 * n + 17 * L + 168) * B
+    kern = {}
+    total = 0.0
+    for k in fetch:
+        fkb, wkb = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
+        kern[k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "fetch_bytes_corrected": 2 * fkb * 1024, "write_bytes": wkb * 1024}
+        total += 2 * fkb * 1024 + wkb * 1024
+    traffic = {
+        "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/run_loglik.py 512 150 3",
+        "workload": "512 instances, L=150, n=462, value+gradient+Hessian (one point_loglik call = terms + assemble kernels)",
+        "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE taken as is; units KB",
+        "kernels": kern, "hbm_bytes_per_launch": total, "algorithmic_bytes_per_launch": alg,
+    }
+    with open(os.path.join(DST, "traffic_point_loglik.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+
+    sq = counters(os.path.join(SRC, "corner_sq", "sq_results.db"), ["corner_tile_kernel"])
+    with open(os.path.join(DST, tag + "_corner_tile_sq_counters.json"), "w") as f:
+        json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT "
+                              "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 tools/run_corner.py 64 3",
+                   "workload": "64 frames 1920x1080, both detectors", "mean_per_launch": sq}, f, indent=1)
+    mf_db = os.path.join(SRC, "qr_mfma", "mfma_results.db")
+    if os.path.exists(mf_db) and not os.path.exists(os.path.join(SRC, "qr_mfma.failed")):
+        mf = counters(mf_db, ["gemm_f64_kernel", "qr_panel_coop_kernel"])
+        with open(os.path.join(DST, tag + "_qr6012_mfma_counters.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA "
+                                  "-- python3 tools/qr_bench.py 6012 6012 1",
+                       "workload": "in-place QR 6012 x 6012 fp64", "mean_per_launch": mf}, f, indent=1)
+    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["avg_ns"] * kv[1]["calls"])[:8]:
+        print("%-80s %6d %12.1f us" % (k[:80], v["calls"], v["avg_ns"] / 1e3))
+    print("point_loglik HBM bytes per launch %.0f (algorithmic %.0f)" % (total, alg))
+
+
+if __name__ == "__main__":
+    main()
