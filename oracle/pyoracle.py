@@ -72,6 +72,15 @@ _lib.orc_log_gaussian.restype = C.c_double
 _lib.orc_trs.restype = C.c_int
 _lib.orc_measurement_update_iekf.restype = C.c_int
 _lib.orc_corner_detect.restype = C.c_int
+_lib.orc_normcdf.restype = C.c_double
+_lib.orc_normcdf.argtypes = [C.c_double]
+_lib.orc_chi2inv.restype = C.c_double
+_lib.orc_chi2inv.argtypes = [C.c_double, C.c_double]
+_lib.orc_individual_compat.restype = C.c_int
+_lib.orc_joint_compat.restype = C.c_int
+_lib.orc_joint_compat.argtypes = [_ip, C.c_int, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]
+_lib.orc_snn_density.restype = C.c_double
+_lib.orc_snn.restype = C.c_double
 
 
 def make_camera(fx, fy, cx, cy, dist, flag, width, height, fov_deg=120.0):
@@ -270,3 +279,41 @@ def corner_detect(gray, params, which, cap=None):
     out = np.zeros(cap, dtype=FEATURE_DTYPE)
     n = _lib.orc_corner_detect(_b(gray), w, h, w, C.byref(params), which, out.ctypes.data_as(C.c_void_p), cap)
     return out[:n].copy()
+
+
+def normcdf(z):
+    return float(_lib.orc_normcdf(float(z)))
+
+
+def chi2inv(p, nu):
+    return float(_lib.orc_chi2inv(float(p), float(nu)))
+
+
+def individual_compat(i, j, y, muY, SYY, chi2LUT):
+    """y: 2 x m (features in columns)."""
+    y, muY, SYY, lut = _F(y), _f64(muY), _F(SYY), _f64(chi2LUT)
+    return bool(_lib.orc_individual_compat(int(i), int(j), y.shape[0], _d(y), _d(muY), _d(SYY), SYY.shape[0], _d(lut)))
+
+
+def joint_compat(idx, sU, y, muY, SYY, chi2LUT):
+    y, muY, SYY, lut = _F(y), _f64(muY), _F(SYY), _f64(chi2LUT)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    s = C.c_double(0.0)
+    ok = _lib.orc_joint_compat(_i(idx), idx.size, float(sU), y.shape[0], _d(y), _d(muY), _d(SYY), _d(lut), C.byref(s))
+    return bool(ok), s.value
+
+
+def snn_density(muY, SYY, y, width, height, enforce_jc=False):
+    y, muY, SYY = _F(y), _f64(muY), _F(SYY)
+    n = muY.size // 2
+    idx = np.zeros(n, dtype=np.int32)
+    s = _lib.orc_snn_density(_d(muY), _d(SYY), n, _d(y), y.shape[1], int(width), int(height), int(enforce_jc), _i(idx))
+    return float(s), idx
+
+
+def snn(mux, Sxx, y, cam, layout=0, enforce_jc=False):
+    mux, Sxx, y = _f64(mux), _F(Sxx), _F(y)
+    n = (mux.size - 12) // 3
+    idx = np.zeros(n, dtype=np.int32)
+    s = _lib.orc_snn(_d(mux), _d(Sxx), mux.size, _d(y), y.shape[1], C.byref(cam), int(layout), int(enforce_jc), _i(idx))
+    return float(s), idx

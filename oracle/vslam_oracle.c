@@ -713,6 +713,174 @@ void orc_affine_sqrt(const double *S, int n, int ldS, const double *C, int m, in
     free(A);
 }
 
+/* ================= data association ================= */
+
+/* src/utility.cpp:20-24 */
+double orc_normcdf(double z) { return 0.5 * erfc(-z / sqrt(2.0)); }
+
+/* Regularised lower incomplete gamma P(a, x): series for x < a + 1, Lentz continued fraction for
+ * Q = 1 - P otherwise. */
+static double gamma_p(double a, double x)
+{
+    if (x <= 0.0) return 0.0;
+    const double lg = lgamma(a);
+    if (x < a + 1.0) {
+        double ap = a, sum = 1.0 / a, del = sum;
+        for (int it = 0; it < 10000; ++it) {
+            ap += 1.0; del *= x / ap; sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        return sum * exp(-x + a * log(x) - lg);
+    }
+    double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, h = d;
+    for (int i = 1; i < 10000; ++i) {
+        double an = -i * (i - a);
+        b += 2.0;
+        d = an * d + b; if (fabs(d) < 1e-300) d = 1e-300;
+        c = b + an / c; if (fabs(c) < 1e-300) c = 1e-300;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-17) break;
+    }
+    return 1.0 - exp(-x + a * log(x) - lg) * h;
+}
+
+/* src/utility.cpp:13-18 */
+double orc_chi2inv(double p, double nu)
+{
+    const double a = nu / 2.0;
+    if (p <= 0.0) return 0.0;
+    double lo = 0.0, hi = a > 1.0 ? a : 1.0;
+    while (gamma_p(a, hi) < p) { lo = hi; hi *= 2.0; }
+    double x = 0.5 * (lo + hi);
+    for (int it = 0; it < 200; ++it) {
+        const double f = gamma_p(a, x) - p;
+        if (f > 0.0) hi = x; else lo = x;
+        const double dens = exp(-x + (a - 1.0) * log(x) - lgamma(a));     /* dP/dx */
+        double xn = x - f / dens;
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (fabs(xn - x) <= 4e-16 * fabs(xn)) { x = xn; break; }
+        x = xn;
+    }
+    return 2.0 * x;
+}
+
+/* src/dataAssociation.cpp:154-177 */
+int orc_individual_compat(int i, int j, int ny, const double *y, const double *muY,
+                          const double *SYY, int N, const double *chi2LUT)
+{
+    double *A = (double *)malloc(sizeof(double) * (size_t)N * ny);
+    for (int c = 0; c < ny; ++c)
+        for (int r = 0; r < N; ++r) A[r + (size_t)N * c] = SYY[r + (size_t)N * (j * ny + c)];   /* :165 */
+    orc_qr_upper(A, N, ny, N);                                                                  /* :167-171 */
+    double t[16];
+    for (int r = 0; r < ny; ++r) t[r] = y[r + (size_t)ny * i] - muY[j * ny + r];
+    trsv_ut(A, ny, N, t);                                                                       /* :172 */
+    double z = 0.0;
+    for (int r = 0; r < ny; ++r) z += t[r] * t[r];
+    free(A);
+    return z < chi2LUT[j];                                                                      /* :175 */
+}
+
+/* src/dataAssociation.cpp:179-285 */
+int orc_joint_compat(const int *idx, int n, double sU, int ny, const double *y, const double *muY,
+                     const double *SYY, const double *chi2LUT, double *surprisal)
+{
+    const int N = n * ny;
+    int nA = 0;
+    for (int j = 0; j < n; ++j) nA += idx[j] != -1;
+    const int k = ny * nA;
+    double *SS = (double *)malloc(sizeof(double) * (size_t)N * (k > 0 ? k : 1));
+    double *t = (double *)malloc(sizeof(double) * (size_t)(k > 0 ? k : 1));
+    int c = 0;
+    for (int j = 0; j < n; ++j) {
+        if (idx[j] == -1) continue;
+        for (int q = 0; q < ny; ++q, ++c) {
+            for (int r = 0; r < N; ++r) SS[r + (size_t)N * c] = SYY[r + (size_t)N * (ny * j + q)];  /* :209-215 */
+            t[c] = y[q + (size_t)ny * idx[j]] - muY[ny * j + q];                                    /* :223-230 */
+        }
+    }
+    double dM2A = 0.0, s2 = 0.0;
+    if (k > 0) {
+        orc_qr_upper(SS, N, k, N);                                                                  /* :217-218 */
+        trsv_ut(SS, k, N, t);                                                                       /* :230 */
+        for (int r = 0; r < k; ++r) { dM2A += t[r] * t[r]; s2 += log(fabs(SS[r + (size_t)N * r])); }
+    }
+    const double halflog2pi = log(M_PI * 2) / 2;
+    const double sA = ny * nA * halflog2pi + s2 + 0.5 * dM2A;                                       /* :233-237 */
+    *surprisal = sA + (n - nA) * sU;                                                                /* :240-243 */
+    free(SS); free(t);
+    return nA > 0 ? dM2A <= chi2LUT[nA - 1] : 1;                                                    /* :276-284 */
+}
+
+/* std::set_difference as the reference calls it (src/dataAssociation.cpp:106) on a second range that is
+ * not sorted: the merge walk is restated literally so that the same features are offered. */
+static int set_difference_walk(const int *a, int na, const int *b, int nb, int *out)
+{
+    int i = 0, j = 0, k = 0;
+    while (i < na && j < nb) {
+        if (a[i] < b[j]) out[k++] = a[i++];
+        else if (b[j] < a[i]) ++j;
+        else { ++i; ++j; }
+    }
+    while (i < na) out[k++] = a[i++];
+    return k;
+}
+
+/* src/dataAssociation.cpp:63-149 */
+double orc_snn_density(const double *muY, const double *SYY, int n, const double *y, int m,
+                       int width, int height, int enforce_jc, int *idx)
+{
+    const int ny = 2, N = ny * n;
+    const double c = 2 * orc_normcdf(3.0) - 1;                                       /* :27-29 */
+    double *lut = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int jj = 0; jj < n; ++jj) lut[jj] = orc_chi2inv(c, ny * (jj + 1));          /* :64-69 */
+    int *midx = (int *)malloc(sizeof(int) * (size_t)m), *diff = (int *)malloc(sizeof(int) * (size_t)m);
+    int *cur = (int *)malloc(sizeof(int) * (size_t)n), *next = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < m; ++i) midx[i] = i;
+    for (int j = 0; j < n; ++j) idx[j] = -1;
+    const double sU = log((double)width) + log((double)height);                      /* :84 */
+    double s = n * sU;
+    (void)N;
+    for (int j = 0; j < n; ++j) {
+        double dsmin = INFINITY, scur = s, snext = 0.0;
+        memcpy(cur, idx, sizeof(int) * (size_t)n);
+        const int nd = set_difference_walk(midx, m, cur, j, diff);                   /* :106 */
+        for (int q = 0; q < nd; ++q) {
+            const int i = diff[q];
+            if (!orc_individual_compat(i, j, ny, y, muY, SYY, ny * n, lut)) continue;   /* :113 */
+            memcpy(next, cur, sizeof(int) * (size_t)n);
+            next[j] = i;
+            const int jc = orc_joint_compat(next, n, sU, ny, y, muY, SYY, lut, &snext);  /* :120 */
+            if (enforce_jc && !jc) continue;
+            const double ds = snext - scur;
+            if (ds < dsmin) { memcpy(idx, next, sizeof(int) * (size_t)n); dsmin = ds; s = snext; }
+        }
+        orc_joint_compat(cur, n, sU, ny, y, muY, SYY, lut, &snext);                  /* :134-135 */
+        const double ds = snext - scur;
+        if (ds < dsmin) { memcpy(idx, cur, sizeof(int) * (size_t)n); s = snext; }    /* :138-142 */
+    }
+    free(lut); free(midx); free(diff); free(cur); free(next);
+    return s;
+}
+
+/* src/dataAssociation.cpp:25-150 */
+double orc_snn(const double *mux, const double *Sxx, int nx_all, const double *y, int m,
+               const orc_camera *cam, int layout, int enforce_jc, int *idx)
+{
+    const int n = (nx_all - 12) / 3, N = 2 * n;
+    double *h = (double *)malloc(sizeof(double) * (size_t)N);
+    double *SR = (double *)calloc((size_t)N * N, sizeof(double));
+    double *C = (double *)calloc((size_t)N * nx_all, sizeof(double));
+    double *SYY = (double *)calloc((size_t)N * N, sizeof(double));
+    orc_bundle_measure(mux, nx_all, cam, layout, h, SR, C, NULL);
+    orc_affine_sqrt(Sxx, nx_all, nx_all, C, N, N, SR, N, SYY, N);                    /* :61 */
+    const double s = orc_snn_density(h, SYY, n, y, m, cam->width, cam->height, enforce_jc, idx);
+    free(h); free(SR); free(C); free(SYY);
+    return s;
+}
+
 /* src/gaussian.cpp:19-36 */
 void orc_condition_on_marginal(const double *muyx, const double *Syx, int ny, int nx, int ld,
                                const double *y, double *mux_out, double *Sx_out, int ldo)

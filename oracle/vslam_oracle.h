@@ -124,6 +124,27 @@ int orc_measurement_update_iekf(const double *mu, const double *S, int n,
                                 double *mu_post, double *S_post,
                                 int *iters, int *cost_evals);
 
+/* ---- data association (src/dataAssociation.cpp, src/utility.cpp) ---- */
+/* normcdf, src/utility.cpp:20-24. */
+double orc_normcdf(double z);
+/* chi2inv(p, nu) = 2 * gamma_p_inv(nu/2, p), src/utility.cpp:13-18 (Boost's inverse of the regularised
+ * lower incomplete gamma function restated as a bracketed Newton iteration on its series /
+ * continued-fraction evaluation). */
+double orc_chi2inv(double p, double nu);
+/* individualCompatibility, src/dataAssociation.cpp:154-177.  y is ny x m column-major, SYY N x N. */
+int orc_individual_compat(int i, int j, int ny, const double *y, const double *muY,
+                          const double *SYY, int N, const double *chi2LUT);
+/* jointCompatibility, src/dataAssociation.cpp:179-285 (idx has n entries, -1 = unassociated). */
+int orc_joint_compat(const int *idx, int n, double sU, int ny, const double *y, const double *muY,
+                     const double *SYY, const double *chi2LUT, double *surprisal);
+/* snn, src/dataAssociation.cpp:25-150, on a precomputed predicted-measurement density (muY, SYY):
+ * greedy surprisal nearest neighbour over landmarks j = 0..n-1 and features 0..m-1.  idx[n] out. */
+double orc_snn_density(const double *muY, const double *SYY, int n, const double *y, int m,
+                       int width, int height, int enforce_jc, int *idx);
+/* The full snn: affineTransform through the landmark bundle first (src/dataAssociation.cpp:50-61). */
+double orc_snn(const double *mux, const double *Sxx, int nx_all, const double *y, int m,
+               const orc_camera *cam, int layout, int enforce_jc, int *idx);
+
 /* ---- image front end (contract defined here; see the .c file) ---- */
 typedef struct {
     int32_t block_size;      /* structure-tensor window, odd, default 7 */

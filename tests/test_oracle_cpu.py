@@ -190,3 +190,71 @@ def test_corner_oracle_hand_checkable():
     corner = np.zeros((40, 40), np.uint8); corner[20:, 20:] = 200
     kp = orc.corner_detect(corner, orc.corner_params(harris_thresh=1e-4), 0)
     assert len(kp) >= 1 and abs(int(kp[0]["x"]) - 20) <= 2 and abs(int(kp[0]["y"]) - 20) <= 2
+
+
+# ---- data association: the reference's own known-answer tests ----
+
+KAT_MUY = np.array([1658.780527, 963.3626597, 433.112825, 731.914696, 1410.293147, 577.2375667])
+KAT_SYY = np.array([[-53.41061755, 9.901075665, 5.306940133, 7.303991992, -5.72141011, 6.609727066],
+                    [0, -37.3526274, 0.08127966678, -22.40730348, -0.2022231471, -15.87273879],
+                    [0, 0, 36.03250166, -22.71362239, -1.725509191, 3.766078776],
+                    [0, 0, 0, -41.70917897, 2.529976157, -8.843062797],
+                    [0, 0, 0, 0, 22.34877992, -22.53303115],
+                    [0, 0, 0, 0, 0, 32.74457988]])
+KAT_Y13 = np.array([[549, 942, 1151, 30, 1381.755157, 1757.892465, 1637.791659, 443.3084837, 279.9869569, 359.2704718,
+                     1363.489534, 1387.401497, 1387.120065],
+                    [855, 625, 1163, 454, 986.4901225, 835.5843074, 1008.082601, 654.6662577, 862.0112818, 747.6976779,
+                     603.0677591, 692.7547721, 563.2515042]])
+KAT_Y3 = np.array([[1754.156364, 1714.701131, 1921.012306], [765.1206969, 934.6000308, 849.6044461]])
+KAT_LUT = [11.829158081900795, 16.251340813956183, 20.062086165714028]
+KAT_SU = 14.832478857591873
+
+
+def test_normcdf_and_chi2inv_reference_kats():
+    """test/src/normcdf.cpp:12,22,32; test/src/chi2inv.cpp:13,25,37,50; chi2 LUT of test/src/jointCompatibility.cpp:89."""
+    from oracle import pyoracle as orc
+    assert abs(orc.normcdf(0) - 0.5) < 1e-15
+    assert abs(orc.normcdf(1) - 0.841344746068543) < 1e-14
+    assert abs(orc.normcdf(2) - 0.977249868051821) < 1e-14
+    for (c, nu), want in (((0.5, 1), 0.454936423119573), ((0.5, 2), 1.386294361119890), ((0.5, 3), 2.365973884375338),
+                          ((0.75, 3), 4.108344935632316)):
+        assert abs(orc.chi2inv(c, nu) - want) <= 1e-13 * want
+    c = 2 * orc.normcdf(3) - 1
+    for k, want in enumerate(KAT_LUT):
+        assert abs(orc.chi2inv(c, 2 * (k + 1)) - want) <= 1e-12 * want
+    assert abs(np.log(1920) + np.log(1440) - KAT_SU) < 1e-12      # the tests' sU is that of a 1920 x 1440 image
+
+
+def test_individual_compatibility_reference_kats():
+    """test/src/individualCompatibility.cpp:11-125."""
+    from oracle import pyoracle as orc
+    got = [orc.individual_compat(i, 0, KAT_Y3, KAT_MUY[:2], KAT_SYY[:2, :2], KAT_LUT[:1]) for i in range(3)]
+    assert got == [False, True, False]
+    expected = [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1]
+    got = [int(orc.individual_compat(i, j, KAT_Y13, KAT_MUY, KAT_SYY, KAT_LUT)) for i in range(13) for j in range(3)]
+    assert got == expected
+
+
+def test_joint_compatibility_reference_kats():
+    """test/src/jointCompatibility.cpp:10-129.  The inputs are printed there to 10 significant digits, so the
+    surprisals reproduce to ~1e-9 only (Catch's Approx accepts 1.2e-5)."""
+    from oracle import pyoracle as orc
+    ok, s = orc.joint_compat([1], KAT_SU, KAT_Y3, KAT_MUY[:2], KAT_SYY[:2, :2], KAT_LUT[:1])
+    assert ok and abs(s - 10.105667572052072) <= 1e-7 * s
+    ok, s = orc.joint_compat([-1], KAT_SU, KAT_Y3, KAT_MUY[:2], KAT_SYY[:2, :2], KAT_LUT[:1])
+    assert ok and abs(s - 14.832478857591873) <= 1e-12 * s
+    ok, s = orc.joint_compat([6, 7, 10], KAT_SU, KAT_Y13, KAT_MUY, KAT_SYY, KAT_LUT)
+    assert ok and abs(s - 33.394861266913537) <= 1e-7 * s
+
+
+def test_snn_on_reference_kat_density():
+    """The greedy search on the density of the 3-landmark / 13-feature known-answer case: landmarks 0 and 1
+    take the features of the reference's compatible association (6, 7); landmark 2 has three individually
+    compatible features (10, 11, 12; test/src/individualCompatibility.cpp:94) and the search must keep the one
+    of least surprisal, which is below the surprisal the reference quotes for (6, 7, 10)."""
+    from oracle import pyoracle as orc
+    s, idx = orc.snn_density(KAT_MUY, KAT_SYY, KAT_Y13, 1920, 1440)
+    cands = {i: orc.joint_compat([6, 7, i], KAT_SU, KAT_Y13, KAT_MUY, KAT_SYY, KAT_LUT)[1] for i in (10, 11, 12)}
+    best = min(cands, key=cands.get)
+    assert idx.tolist() == [6, 7, best]
+    assert s == cands[best] and s <= 33.394861266913537
