@@ -188,6 +188,35 @@ vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver);
  * VSLAM_TRS_EIG = host eigenvalue route), -1 before the first update.  Diagnostic. */
 int vslam_ctx_last_trs_route(const vslam_ctx *ctx);
 
+/* ---- data association ----
+ * normcdf and chi2inv, src/utility.cpp:13-24 (host). */
+double vslam_normcdf(double z);
+double vslam_chi2inv(double p, double nu);
+/* individualCompatibility, src/dataAssociation.cpp:154-177, for every pair at once:
+ * compat[i*n + j] = feature i (column i of the 2 x m matrix y) is compatible with landmark j.
+ * muY[2n], SYY (2n x 2n upper, ld ldS), chi2LUT[n]. */
+vslam_status vslam_individual_compat(vslam_ctx *ctx, const double *y, int m, const double *muY, const double *SYY,
+                                     int n, int ldS, const double *chi2LUT, uint8_t *compat);
+/* jointCompatibility, src/dataAssociation.cpp:179-285: idx[n] (feature of landmark j or -1). */
+vslam_status vslam_joint_compat(vslam_ctx *ctx, const int32_t *idx, int n, double sU, const double *y, int m,
+                                const double *muY, const double *SYY, int ldS, const double *chi2LUT,
+                                double *surprisal, int32_t *compatible);
+/* The search of snn, src/dataAssociation.cpp:63-149, on a given predicted-measurement density;
+ * the chi2 table and the per-landmark surprisal log(width)+log(height) are formed as there. */
+vslam_status vslam_snn_density(vslam_ctx *ctx, const double *muY, const double *SYY, int n, int ldS, const double *y, int m,
+                               int width, int height, int enforce_jc, int32_t *idx, double *surprisal);
+/* Device-pointer batch of independent instances (one workgroup each): instance b reads muY + b*stride_mu,
+ * SYY + b*stride_S, y + b*stride_y (2 x m), writes idx + b*n and surprisal[b].  Queued, not synchronised. */
+vslam_status vslam_snn_density_batch_dev(vslam_ctx *ctx, int batch, const double *muY, size_t stride_mu,
+                                         const double *SYY, int ldS, size_t stride_S, int n,
+                                         const double *y, size_t stride_y, int m, int width, int height,
+                                         int enforce_jc, int32_t *idx, double *surprisal);
+/* snn(mux, Sxx, y, param, idx, enforceJointCompatibility), src/dataAssociation.cpp:25-150 as called at
+ * src/SLAM.cpp:396,533: affineTransform through the landmark bundle, then the search.  Returns the
+ * surprisal through *surprisal; idx[(nx_all-12)/3]. */
+vslam_status vslam_snn(vslam_ctx *ctx, const vslam_camera *cam, const double *mux, const double *Sxx, int nx_all, int ldS,
+                       int layout, const double *y, int m, int enforce_jc, int32_t *idx, double *surprisal);
+
 /* ---- corner front end ----
  * The feature stage of detectAndDrawORB, src/imagefeatures.cpp:71-96, reduced
  * to what the caller consumes (src/SLAM.cpp:449-472): keypoints with a

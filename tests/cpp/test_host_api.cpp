@@ -245,6 +245,40 @@ static void test_condition_on_marginal()
     CHECK_NEAR(mc(1), 4.0 - 0.6 * (0.5 / 3.0), 1e-13);
 }
 
+// test/src/individualCompatibility.cpp:11-60, test/src/jointCompatibility.cpp:10-82,85-129, test/src/chi2inv.cpp
+static void test_data_association(const std::string &xml)
+{
+    CHECK_NEAR(chi2inv(0.5, 1), 0.454936423119573, 1e-12);
+    CHECK_NEAR(chi2inv(0.75, 3), 4.108344935632316, 1e-12);
+    CHECK_NEAR(normcdf(1), 0.841344746068543, 1e-13);
+    Vector muY{1658.780527, 963.3626597};
+    Matrix SYY(2, 2), y(2, 3);
+    SYY(0, 0) = -53.41061755; SYY(0, 1) = 9.901075665; SYY(1, 1) = -37.3526274;
+    const double ys[2][3] = {{1754.156364, 1714.701131, 1921.012306}, {765.1206969, 934.6000308, 849.6044461}};
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) y(r, c) = ys[r][c];
+    std::vector<double> lut{11.829158081900795};
+    CHECK_TRUE(individualCompatibility(0, 0, 2, y, muY, SYY, lut) == false);
+    CHECK_TRUE(individualCompatibility(1, 0, 2, y, muY, SYY, lut) == true);
+    CHECK_TRUE(individualCompatibility(2, 0, 2, y, muY, SYY, lut) == false);
+    double surprisal = 0.0;
+    const double sU = 14.832478857591873;
+    CHECK_TRUE(jointCompatibility(std::vector<int>{1}, sU, 2, y, muY, SYY, lut, surprisal) == true);
+    CHECK_NEAR(surprisal, 10.105667572052072, 1e-7);
+    CHECK_TRUE(jointCompatibility(std::vector<int>{-1}, sU, 2, y, muY, SYY, lut, surprisal) == true);
+    CHECK_NEAR(surprisal, 14.832478857591873, 1e-12);
+    // snn on a scene whose features are the noisy projections of its landmarks in reverse order
+    Scene sc(xml, 5, 9);
+    Vector h;
+    MeasurementPointLandmarkBundle()(sc.x, sc.param.camera_param, h);
+    Matrix feats(2, 5);
+    for (int j = 0; j < 5; ++j) { feats(0, 4 - j) = h(2 * j) + 0.5; feats(1, 4 - j) = h(2 * j + 1) - 0.5; }
+    std::vector<int> idx;
+    const double s = snn(sc.x, sc.S, feats, sc.param.camera_param, idx);
+    CHECK_TRUE(idx.size() == 5);
+    for (int j = 0; j < 5; ++j) CHECK_TRUE(idx[(size_t)j] == 4 - j);
+    CHECK_TRUE(s < 5 * (std::log(sc.param.camera_param.cam.width) + std::log(sc.param.camera_param.cam.height)));
+}
+
 static void test_detect_corners()
 {
     const int w = 320, h = 240;
@@ -273,6 +307,7 @@ int main(int argc, char **argv)
         test_point_log_likelihood(argv[1]);
         test_measurement_update(argv[1]);
         test_detect_corners();
+        test_data_association(argv[1]);
         // Contract violations surface as exceptions carrying the library's message, not aborts.
         bool threw = false;
         try {

@@ -102,6 +102,11 @@ def _declare(L):
         "vslam_cost_joint_density": [_vp, C.POINTER(Camera), _vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _vp],
         "vslam_measurement_update_iekf": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _vp, _d,
                                           _vp, _vp, _i, _vp, _vp, _vp],
+        "vslam_individual_compat": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp],
+        "vslam_joint_compat": [_vp, _vp, _i, _d, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
+        "vslam_snn_density": [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp],
+        "vslam_snn_density_batch_dev": [_vp, _i, _vp, _sz, _vp, _i, _sz, _i, _vp, _sz, _i, _i, _i, _i, _vp, _vp],
+        "vslam_snn": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
         "vslam_corner_detect": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
         "vslam_corner_response": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _vp, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
@@ -113,6 +118,10 @@ def _declare(L):
         fn.restype = C.c_int32
         fn.argtypes = args
     L.vslam_has_device_code.restype = C.c_int
+    L.vslam_normcdf.restype = C.c_double
+    L.vslam_normcdf.argtypes = [_d]
+    L.vslam_chi2inv.restype = C.c_double
+    L.vslam_chi2inv.argtypes = [_d, _d]
 
 
 def check(status, ctx=None):

@@ -216,6 +216,53 @@ def measurement_update_iekf(ctx, cam, mu, S, y, visible, sigma):
     return int(info[0]), mup, Sp, int(info[1]), int(info[2])
 
 
+def normcdf(z):
+    return float(_lib.lib().vslam_normcdf(float(z)))
+
+
+def chi2inv(p, nu):
+    return float(_lib.lib().vslam_chi2inv(float(p), float(nu)))
+
+
+def individual_compat(ctx, y, muY, SYY, chi2LUT):
+    """All (feature i, landmark j) pairs: bool array (m, n).  y is 2 x m (features in columns)."""
+    y, muY, SYY, lut = _F(y), _f64(muY), _F(SYY), _f64(chi2LUT)
+    m, n = y.shape[1], muY.size // 2
+    out = np.zeros((m, n), dtype=np.uint8)
+    check(ctx._L.vslam_individual_compat(ctx.ptr, _p(y), m, _p(muY), _p(SYY), n, SYY.shape[0], _p(lut), _p(out)), ctx.ptr)
+    return out.astype(bool)
+
+
+def joint_compat(ctx, idx, sU, y, muY, SYY, chi2LUT):
+    y, muY, SYY, lut = _F(y), _f64(muY), _F(SYY), _f64(chi2LUT)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    s = np.zeros(1)
+    jc = np.zeros(1, dtype=np.int32)
+    check(ctx._L.vslam_joint_compat(ctx.ptr, _p(idx), idx.size, float(sU), _p(y), y.shape[1], _p(muY), _p(SYY), SYY.shape[0],
+                                    _p(lut), _p(s), _p(jc)), ctx.ptr)
+    return bool(jc[0]), float(s[0])
+
+
+def snn_density(ctx, muY, SYY, y, width, height, enforce_jc=False):
+    y, muY, SYY = _F(y), _f64(muY), _F(SYY)
+    n = muY.size // 2
+    idx = np.zeros(n, dtype=np.int32)
+    s = np.zeros(1)
+    check(ctx._L.vslam_snn_density(ctx.ptr, _p(muY), _p(SYY), n, SYY.shape[0], _p(y), y.shape[1], int(width), int(height),
+                                   int(enforce_jc), _p(idx), _p(s)), ctx.ptr)
+    return float(s[0]), idx
+
+
+def snn(ctx, cam, mux, Sxx, y, layout=LAYOUT_COMPAT, enforce_jc=False):
+    mux, Sxx, y = _f64(mux), _F(Sxx), _F(y)
+    n = (mux.size - 12) // 3
+    idx = np.zeros(n, dtype=np.int32)
+    s = np.zeros(1)
+    check(ctx._L.vslam_snn(ctx.ptr, C.byref(cam), _p(mux), _p(Sxx), mux.size, mux.size, layout, _p(y), y.shape[1],
+                           int(enforce_jc), _p(idx), _p(s)), ctx.ptr)
+    return float(s[0]), idx
+
+
 def corner_detect(ctx, gray, params, detector=HARRIS, cap=None):
     gray = np.ascontiguousarray(gray, dtype=np.uint8)
     h, w = gray.shape
@@ -251,6 +298,14 @@ def point_loglik_batch_dev(ctx, cam, n, x, y, visible, sigma, value, g=None, H=N
 
 def qr_upper_batch_dev(ctx, A, rows, cols, lda, batch, stride):
     check(ctx._L.vslam_qr_upper_batch_dev(ctx.ptr, _tp(A), rows, cols, lda, stride, batch), ctx.ptr)
+
+
+def snn_density_batch_dev(ctx, muY, SYY, y, n, m, width, height, idx, surprisal, enforce_jc=False):
+    """torch tensors on the GPU: muY (B, 2n) f64, SYY (B, 2n, 2n) column-major per instance (i.e. the transpose
+    of the row-major view), y (B, m, 2) = column-major 2 x m, idx (B, n) int32, surprisal (B,) f64."""
+    B, N = muY.shape[0], 2 * n
+    check(ctx._L.vslam_snn_density_batch_dev(ctx.ptr, B, _tp(muY), N, _tp(SYY), N, N * N, n, _tp(y), 2 * m, m, int(width),
+                                             int(height), int(enforce_jc), _tp(idx), _tp(surprisal)), ctx.ptr)
 
 
 def corner_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, params, detector, out, cap, count):

@@ -10,6 +10,9 @@
 //   measurementUpdateIEKF                         src/gaussian.hpp:30-131,469-532
 //   conditionGaussianOnMarginal                   src/gaussian.cpp:19-36
 //   Feature, detectCorners                        src/imagefeatures.h:15-19,37
+//   chi2inv, normcdf                              src/utility.cpp:13-24
+//   individualCompatibility, jointCompatibility,
+//   snn                                           src/dataAssociation.h:10-12
 // The reference passes Eigen objects; Eigen is not a dependency here, so the
 // mirror uses two tiny column-major value types (Vector, Matrix) with the same
 // resize / data / rows / cols surface.  With Eigen available the functors accept
@@ -265,6 +268,48 @@ int measurementUpdateIEKF(const Vec &mux, const Mat &Sxx, const Vec &, const Vec
 // Opt-in: solve the trust-region subproblems of measurementUpdateIEKF on the device from Cholesky
 // factors instead of the reference's host eigendecomposition (same iterates; see vslam_hip.h).
 inline void useDeviceTrustRegion(bool on) { check(vslam_ctx_set_trs_solver(context(), on ? VSLAM_TRS_CHOLESKY : VSLAM_TRS_EIG)); }
+
+// ---- data association -------------------------------------------------------
+inline double chi2inv(double p, double nu) { return vslam_chi2inv(p, nu); }
+inline double normcdf(double z) { return vslam_normcdf(z); }
+
+// y is 2 x m (features in columns), SYY upper triangular (2n x 2n).
+template <class Mat, class Vec>
+bool individualCompatibility(const int &i, const int &j, const int &ny, const Mat &y, const Vec &muY, const Mat &SYY,
+                             const std::vector<double> &chi2LUT)
+{
+    if (ny != 2 || (int)y.rows() != ny || i < 0 || j < 0 || i >= (int)y.cols()) throw std::runtime_error("individualCompatibility: bad arguments");
+    const int n = (int)muY.rows() / 2, m = (int)y.cols();
+    std::vector<uint8_t> all((size_t)m * n);
+    check(vslam_individual_compat(context(), y.data(), m, muY.data(), SYY.data(), n, (int)SYY.rows(), chi2LUT.data(), all.data()));
+    return all[(size_t)i * n + j] != 0;
+}
+
+template <class Mat, class Vec>
+bool jointCompatibility(const std::vector<int> &idx, const double &sU, const int &ny, const Mat &y, const Vec &muY, const Mat &SYY,
+                        const std::vector<double> &chi2LUT, double &surprisal)
+{
+    if (ny != 2 || (int)y.rows() != ny || (int)idx.size() * ny != (int)muY.rows()) throw std::runtime_error("jointCompatibility: bad arguments");
+    std::vector<int32_t> id(idx.begin(), idx.end());
+    int32_t jc = 0;
+    check(vslam_joint_compat(context(), id.data(), (int)id.size(), sU, y.data(), (int)y.cols(), muY.data(), SYY.data(), (int)SYY.rows(),
+                             chi2LUT.data(), &surprisal, &jc));
+    return jc != 0;
+}
+
+// snn(mux, Sxx, y, param, idx, enforceJointCompatibility), src/dataAssociation.cpp:25-150; returns the surprisal.
+template <class Vec, class Mat>
+double snn(const Vec &mux, const Mat &Sxx, const Mat &y, const CameraParameters &param, std::vector<int> &idx,
+           bool enforceJointCompatibility = false, int layout = VSLAM_LAYOUT_COMPAT)
+{
+    const int n = ((int)mux.rows() - 12) / 3;
+    std::vector<int32_t> id((size_t)(n > 0 ? n : 0));
+    double s = 0.0;
+    check(vslam_snn(context(), &param.cam, mux.data(), Sxx.data(), (int)mux.rows(), (int)Sxx.rows(), layout, y.data(), (int)y.cols(),
+                    enforceJointCompatibility ? 1 : 0, id.data(), &s));
+    idx.assign(id.begin(), id.end());
+    return s;
+}
 
 // ---- corner front end ---------------------------------------------------------
 using Feature = vslam_feature;         // {int x; int y; float score;}, src/imagefeatures.h:15-19
