@@ -124,3 +124,17 @@ def test_batch_dev_both_detectors(ctx):
             assert np.array_equal(got[:, 0], want["x"]) and np.array_equal(got[:, 1], want["y"])
             assert np.array_equal(got[:, 2].view(np.uint32), want["score"].view(np.uint32))
     tctx.close()
+
+
+@pytest.mark.gpu
+def test_sqrtf_is_correctly_rounded_on_device(ctx):
+    """The Shi-Tomasi response uses sqrtf; the bit-exact contract needs it correctly rounded for every
+    non-negative finite float (checked against the fp64 square root rounded once)."""
+    import ctypes as C
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    L.vslam_debug_sqrtf_mismatches.restype = C.c_int32
+    L.vslam_debug_sqrtf_mismatches.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    bad = C.c_ulonglong(1)
+    assert L.vslam_debug_sqrtf_mismatches(ctx.ptr, C.byref(bad)) == 0
+    assert bad.value == 0

@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
                 }
                 if (DET & 2) {
                     const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
-                    // correctly rounded float sqrt via fp64 (53 >= 2*24+2 bits: the double rounding is exact)
-                    const float root = (float)sqrt((double)__fadd_rn(__fmul_rn(d, d), t2));
+                    // sqrtf is the correctly rounded square root under this build's flags (no fast-math); the
+                    // exhaustive comparison with (float)sqrt((double)x) is vslam_debug_sqrtf_mismatches below
+                    const float root = sqrtf(__fadd_rn(__fmul_rn(d, d), t2));
                     resp_s[i] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
                 }
             }
@@ -489,9 +490,36 @@ static vslam_status ensure_lds_attr(vslam_ctx *ctx)
     return VSLAM_OK;
 }
 
+// Counts the non-negative finite floats x for which sqrtf(x) differs from the correctly rounded
+// square root (float)sqrt((double)x) (exact: 53 >= 2*24 + 2 bits).
+__global__ void sqrtf_check_kernel(unsigned long long *bad)
+{
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine = 0;
+    for (unsigned long long u = tid; u < 0x7f800000ull; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)u);
+        mine += __float_as_uint(sqrtf(x)) != __float_as_uint((float)sqrt((double)x));
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 }  // namespace vslam
 
 using namespace vslam;
+
+// Test hook (not part of the public header): the Shi-Tomasi response relies on sqrtf being correctly rounded.
+extern "C" vslam_status vslam_debug_sqrtf_mismatches(vslam_ctx *ctx, unsigned long long *count)
+{
+    if (!ctx || !count) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ws_reserve(ctx, 256));
+    unsigned long long *d = static_cast<unsigned long long *>(ctx->ws);
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(sqrtf_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, d);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(d2h(ctx, count, d, 8));
+    return stream_finish(ctx);
+}
 
 extern "C" vslam_status vslam_corner_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
                                                       size_t stride_frame, int frames, const vslam_corner_params *params,
