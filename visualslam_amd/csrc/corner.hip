@@ -31,7 +31,7 @@
 
 namespace vslam {
 
-constexpr int TW = 64, TH = 16;            // output tile: 40 KB of LDS, four workgroups per CU (64x32 tiles: two, 25% slower)
+constexpr int TW = 64, TH = 16;            // output tile: 40 KB of LDS, four workgroups per CU (measured: 64x32 -40%, 64x8 -23%)
 constexpr int MAXHB = 7;                   // block_size <= 15
 constexpr int SORT_S = 16384;              // keys per LDS sort
 constexpr int CAND_CHUNKS = 4;             // candidate capacity = 4 * SORT_S per frame and detector
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     {
         const int gx0 = x0 - halo, gy0 = y0 - halo;
         const int ax0 = gx0 & ~3;
-        const int ND = ((gx0 + IW - 1) >> 2) - (ax0 >> 2) + 1;
+        // x0 is a multiple of 4, so the number of aligned words per row does not depend on the tile
+        const int ND = BS > 0 ? (((TW + BS / 2 + 2 - 1) >> 2) - ((-(BS / 2 + 2)) >> 2) + 1) : ((gx0 + IW - 1) >> 2) - (ax0 >> 2) + 1;
         const bool fast_ok = ((a.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
         // every thread's row words are requested before any is unpacked (at most MAXIT rounds of 256 items)
         constexpr int MAXIT = ((TW + 2 * (MAXHB + 2) + 6) / 4 + 1) * (TH + 2 * (MAXHB + 2)) / 256 + 1;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int lx = gx + b - gx0;
-                    if (lx >= 0 && lx < IW) img[r * IP + lx] = (int32_t)((words[it] >> (8 * b)) & 255u);
+                    if (lx >= 0 && lx < IW) img[__mul24(r, IP) + lx] = (int32_t)((words[it] >> (8 * b)) & 255u);
                 }
             }
         }
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
         constexpr int NSEG = 9, SEG = 8;           // GW = 72 = 9 segments of 8 columns
         for (int item = tid; item < GH * NSEG; item += 256) {
             const int ly = item / NSEG, xb = (item - ly * NSEG) * SEG;
-            const int32_t *r0 = img + ly * IP + xb;
+            const int32_t *r0 = img + __mul24(ly, IP) + xb;
             int v0[SEG + 2], v1[SEG + 2], v2[SEG + 2];
 #pragma unroll
             for (int k = 0; k < SEG + 2; ++k) { v0[k] = r0[k]; v1[k] = r0[IP + k]; v2[k] = r0[2 * IP + k]; }
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
             for (int k = 0; k < SEG; ++k) {
                 const int ix = (v0[k + 2] - v0[k]) + 2 * (v1[k + 2] - v1[k]) + (v2[k + 2] - v2[k]);
                 const int iy = (v2[k] - v0[k]) + 2 * (v2[k + 1] - v0[k + 1]) + (v2[k + 2] - v0[k + 2]);
-                const int p = ly * GP + xb + k;
-                pa[p] = ix * ix; pb[p] = iy * iy; pc[p] = ix * iy;
+                const int p = __mul24(ly, GP) + xb + k;
+                pa[p] = __mul24(ix, ix); pb[p] = __mul24(iy, iy); pc[p] = __mul24(ix, iy);   // |ix|, |iy| <= 1020
             }
         }
     } else {
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
         constexpr int NSEG = 9, SEG = 8;           // RW = 66 <= 72
         for (int item = tid; item < GH * NSEG; item += 256) {
             const int ly = item / NSEG, xb = (item - ly * NSEG) * SEG;
-            const int32_t *qa = pa + ly * GP, *qb = pb + ly * GP, *qc = pc + ly * GP;
+            const int rowoff = __mul24(ly, GP);
+            const int32_t *qa = pa + rowoff, *qb = pb + rowoff, *qc = pc + rowoff;
             int va[SEG + 6], vb[SEG + 6], vc[SEG + 6];
 #pragma unroll
             for (int k = 0; k < SEG + 6; ++k) {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 #pragma unroll
             for (int k = 0; k < SEG; ++k) {
                 if (k > 0) { sa += va[k + 6] - va[k - 1]; sb += vb[k + 6] - vb[k - 1]; sc += vc[k + 6] - vc[k - 1]; }
-                if (xb + k < RW) { const int o = ly * RP + xb + k; ha[o] = sa; hbb[o] = sb; hc[o] = sc; }
+                if (xb + k < RW) { const int o = __mul24(ly, RP) + xb + k; ha[o] = sa; hbb[o] = sb; hc[o] = sc; }
             }
         }
     } else {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
             if (BS == 7) {
 #pragma unroll
                 for (int t = 0; t < VROWS; ++t) {
-                    const int q = min(yb + t, GH - 1) * RP + lx;
+                    const int q = __mul24(min(yb + t, GH - 1), RP) + lx;
                     ca[t] = ha[q]; cb[t] = hbb[q]; cc[t] = hc[q];
                 }
 #pragma unroll
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
                 const bool valid = gx >= R && gy >= R && gx < w - R && gy < h - R;
                 const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
                 const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
-                const int i = ly * RP + lx;
+                const int i = __mul24(ly, RP) + lx;
                 if (DET & 1) {
                     const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
                     const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
         const int ly = i >> 6, lx = i & 63;
         const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= w || gy >= h) continue;
-        const int c = (ly + 1) * RP + (lx + 1);
+        const int c = __mul24(ly + 1, RP) + (lx + 1);
         if (MAPS) {
             if ((DET & 1) && a.map_h) a.map_h[(size_t)gy * w + gx] = resp_h[c];
             if ((DET & 2) && a.map_s) a.map_s[(size_t)gy * w + gx] = resp_s[c];
