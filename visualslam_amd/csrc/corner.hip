@@ -555,7 +555,6 @@ extern "C" vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray,
     uint8_t *dimg = ar.take<uint8_t>(img_bytes);
     vslam_feature *dout = ar.take<vslam_feature>((size_t)ndet * cap);
     int32_t *dcount = ar.take<int32_t>(2);
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d(ctx, dimg, gray, img_bytes));
     CornerArgs a = make_args(dimg, w, h, stride, 0, params);
     VSLAM_TRY(launch_detect(ctx, a, 1, detector, params, dout, cap, dcount, dws));

@@ -209,7 +209,6 @@ extern "C" vslam_status vslam_log_gaussian(vslam_ctx *ctx, const double *x, cons
     double *dS = ar.take<double>(nn), *dval = ar.take<double>(1);
     double *dH = H ? ar.take<double>(nn) : nullptr, *dW = H ? ar.take<double>(nn) : nullptr;
     void *tws = H ? ar.take<char>(trtri_ws_bytes(n)) : nullptr;
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     VSLAM_TRY(h2d(ctx, dmu, mu, n * 8));
     VSLAM_TRY(h2d_2d(ctx, dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
@@ -233,7 +232,6 @@ extern "C" vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n
     Arena ar(ctx->ws);
     double *dS = ar.take<double>((size_t)n * n), *dC = ar.take<double>((size_t)m * n), *dA = ar.take<double>((size_t)rows * m);
     void *qws = ar.take<char>(qr_ws_bytes(rows, m, 1));
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d_2d(ctx, dS, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
     VSLAM_TRY(h2d_2d(ctx, dC, (size_t)m * 8, C, (size_t)ldC * 8, (size_t)m * 8, n));
     VSLAM_TRY(h2d_2d(ctx, dA + n, (size_t)rows * 8, SR, (size_t)ldSR * 8, (size_t)m * 8, m));
@@ -390,7 +388,6 @@ extern "C" vslam_status vslam_cost_joint_density(vslam_ctx *ctx, const vslam_cam
     VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n)));
     CostDevice c;
     cost_carve(ctx->ws, n, &c);
-    hipStream_t s = ctx->stream;
     const size_t nn = (size_t)n * n;
     VSLAM_TRY(h2d(ctx, c.x, x, n * 8));
     VSLAM_TRY(h2d(ctx, c.mu, mu, n * 8));

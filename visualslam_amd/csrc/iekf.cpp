@@ -190,6 +190,17 @@ extern "C" vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver)
     return VSLAM_OK;
 }
 
+// Test hook (not part of the public header): the host eigensolver of the eigenvalue route.
+extern "C" void vslam_debug_sym_eig(const double *H, int n, double *Q, double *v) { sym_eig_host(H, n, Q, v); }
+// Test hook: the trust-region subproblem in the eigenbasis (src/fmin.cpp:40-131); returns trs's code.
+extern "C" int vslam_debug_trs(const double *Q, const double *v, const double *g, int n, double D, double *p)
+{
+    std::vector<double> pv;
+    const int ret = trs_host(Q, v, g, n, D, pv);
+    for (int i = 0; i < n; ++i) p[i] = pv[(size_t)i];
+    return ret;
+}
+
 extern "C" int vslam_ctx_last_trs_route(const vslam_ctx *ctx) { return ctx ? ctx->trs_last : -1; }
 
 extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out);
@@ -211,7 +222,6 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     VSLAM_TRY(ws_reserve(ctx, cost_ws_bytes(n) + (try_device ? newton_ws_bytes(n) : 0)));
     CostDevice c;
     cost_carve(ctx->ws, n, &c);
-    hipStream_t s = ctx->stream;
     const size_t nn = (size_t)n * n;
     VSLAM_TRY(h2d(ctx, c.mu, mu, n * 8));
     VSLAM_TRY(h2d_2d(ctx, c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));

@@ -244,7 +244,6 @@ extern "C" vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera 
     int32_t *dc = ar.take<int32_t>(L);
     double *dC = C ? ar.take<double>((size_t)m * n) : nullptr;
     double *dSR = SR ? ar.take<double>((size_t)m * m) : nullptr;
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     VSLAM_TRY(launch_bundle_measure(ctx, k, dx, n, layout, dh, dSR, dC, dc));
     VSLAM_TRY(d2h(ctx, h, dh, m * 8));

@@ -469,7 +469,6 @@ extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *c
     int32_t *dc = ar.take<int32_t>(L);
     double *dval = ar.take<double>(1);
     double *dH = H ? ar.take<double>(nn) : nullptr;
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     VSLAM_TRY(h2d(ctx, dy, y, 2 * L * 8));
     VSLAM_TRY(h2d(ctx, dv, visible, L));

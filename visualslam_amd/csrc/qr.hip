@@ -422,8 +422,10 @@ __global__ __launch_bounds__(256) void qr_block_solve_kernel(const double *Ypart
     for (int idx = tid; idx < ob * SOLVE_CT; idx += 256) {
         const int row = idx % ob, c = idx / ob, col = c0 + c;
         double v = 0.0;
-        if (col < n2)
+        if (col < n2) {
+#pragma unroll 8
             for (int sidx = 0; sidx < ks; ++sidx) v += Y[(size_t)sidx * strideSplit + (size_t)col * ldy + row];
+        }
         Ys[row][c] = v;
     }
     const int np = (ob + NB - 1) / NB;
@@ -775,7 +777,6 @@ extern "C" vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int 
     Arena ar(ctx->ws);
     double *dA = ar.take<double>((size_t)rows * cols);
     void *qws = ar.take<char>(qr_ws_bytes(rows, cols, 1));
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d_2d(ctx, dA, (size_t)rows * 8, A, (size_t)lda * 8, (size_t)rows * 8, cols));
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, cols, rows, 0, 1, qws));
     VSLAM_TRY(d2h_2d(ctx, A, (size_t)lda * 8, dA, (size_t)rows * 8, (size_t)rows * 8, cols));
@@ -795,7 +796,6 @@ extern "C" vslam_status vslam_debug_gemm(vslam_ctx *ctx, int M, int N, int K, in
     Arena ar(ctx->ws);
     double *dA = ar.take<double>((size_t)lda * colsA), *dB = ar.take<double>((size_t)ldb * colsB), *dC = ar.take<double>((size_t)ldc * N);
     double *dS = ar.take<double>((size_t)ldc * N * ks);
-    hipStream_t s = ctx->stream;
     VSLAM_TRY(h2d(ctx, dA, A, ba));
     VSLAM_TRY(h2d(ctx, dB, B, bb));
     VSLAM_TRY(h2d(ctx, dC, C, bc));
