@@ -217,6 +217,24 @@ vslam_status vslam_snn_density_batch_dev(vslam_ctx *ctx, int batch, const double
 vslam_status vslam_snn(vslam_ctx *ctx, const vslam_camera *cam, const double *mux, const double *Sxx, int nx_all, int ldS,
                        int layout, const double *y, int m, int enforce_jc, int32_t *idx, double *surprisal);
 
+/* ---- time update ----
+ * timeUpdateContinuous(mukm1, Skm1, u, SlamProcessModel, param, timestep, muk, Sk), src/gaussian.hpp:337-383
+ * as called at src/SLAM.cpp:250,337,507: the RK4 step with Jacobian propagation (RK4SDEHelper,
+ * src/gaussian.hpp:171-239) of SlamProcessModel (src/model.cpp:9-136) pushed through affineTransform.
+ * pos_tune / ori_tune are SlamParameters::position_tune / orientation_tune (3 x 3 column-major,
+ * src/model.hpp:17-18); the input u is unused by the reference's process model and has no argument
+ * here.  S and S_out are n x n column-major (upper-triangular square-root covariance; S_out may be S,
+ * mu_out may be mu).  The reference's 3n x n Householder QR keeps its R: the rows that are
+ * identically zero are left out. */
+vslam_status vslam_time_update(vslam_ctx *ctx, const double *mu, const double *S, int n, int ldS,
+                               const double *pos_tune, const double *ori_tune, double dt,
+                               double *mu_out, double *S_out, int ldSout);
+/* Device-pointer batch of independent filters: mu + b*n, S + b*n*n (ld n), same for the outputs.
+ * pos_tune / ori_tune are host pointers.  Queued on the context's stream, not synchronised. */
+vslam_status vslam_time_update_batch_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int batch,
+                                         const double *pos_tune, const double *ori_tune, double dt,
+                                         double *mu_out, double *S_out);
+
 /* ---- corner front end ----
  * The feature stage of detectAndDrawORB, src/imagefeatures.cpp:71-96, reduced
  * to what the caller consumes (src/SLAM.cpp:449-472): keypoints with a

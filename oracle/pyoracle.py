@@ -252,6 +252,34 @@ def measurement_update_iekf(mu, S, y, visible, cam, sigma):
     return ret, mup, Sp, it.value, ev.value
 
 
+def process_model(x, pos_tune, ori_tune, want_SQ=True, want_J=True):
+    x, pt, ot = _f64(x), _F(pos_tune), _F(ori_tune)
+    n = x.size
+    f = np.zeros(n)
+    SQ = np.zeros((n, n), order="F") if want_SQ else None
+    J = np.zeros((n, n), order="F") if want_J else None
+    _lib.orc_process_model(_d(x), n, _d(pt), _d(ot), _d(f), _d(SQ), _d(J))
+    return f, SQ, J
+
+
+def rk4_sde(xdw, pos_tune, ori_tune, dt, want_J=True):
+    xdw, pt, ot = _f64(xdw), _F(pos_tune), _F(ori_tune)
+    n = xdw.size // 2
+    xn = np.zeros(n)
+    J = np.zeros((n, 2 * n), order="F") if want_J else None
+    _lib.orc_rk4_sde(_d(xdw), n, _d(pt), _d(ot), C.c_double(dt), _d(xn), _d(J))
+    return xn, J
+
+
+def time_update(mu, S, pos_tune, ori_tune, dt):
+    mu, S, pt, ot = _f64(mu), _F(S), _F(pos_tune), _F(ori_tune)
+    n = mu.size
+    mup = np.zeros(n)
+    Sp = np.zeros((n, n), order="F")
+    _lib.orc_time_update(_d(mu), _d(S), n, n, _d(pt), _d(ot), C.c_double(dt), _d(mup), _d(Sp), n)
+    return mup, Sp
+
+
 def corner_params(block_size=7, border=None, max_features=10000, harris_k=0.04,
                   harris_thresh=1e-4, shi_thresh=1e-3):
     p = CornerParams()

@@ -713,6 +713,144 @@ void orc_affine_sqrt(const double *S, int n, int ldS, const double *C, int m, in
     free(A);
 }
 
+/* ================= time update ================= */
+
+/* SlamProcessModel, src/model.cpp:9-136.  f (n); SQ (n x n, or NULL): position_tune /
+ * orientation_tune (3x3 column-major) on the diagonal blocks 0-2 and 3-5; dfdx (n x n, or NULL). */
+void orc_process_model(const double *x, int n, const double *pos_tune, const double *ori_tune,
+                       double *f, double *SQ, double *dfdx)
+{
+    double Rnc[9], T[9];                                     /* column-major 3x3 */
+    const double phi = x[9], theta = x[10], psi = x[11];
+    orc_rpy2rot(x + 9, Rnc);
+    T[0] = 1; T[3] = sin(phi) * tan(theta); T[6] = cos(phi) * tan(theta);
+    T[1] = 0; T[4] = cos(phi);              T[7] = -sin(phi);
+    T[2] = 0; T[5] = sin(phi) / cos(theta); T[8] = cos(phi) / cos(theta);
+    for (int i = 0; i < n; ++i) f[i] = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < 3; ++k) { a += Rnc[i + 3 * k] * x[k]; b += T[i + 3 * k] * x[3 + k]; }
+        f[6 + i] = a; f[9 + i] = b;
+    }
+    if (SQ) {
+        for (size_t i = 0; i < (size_t)n * n; ++i) SQ[i] = 0.0;
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) {
+                SQ[r + (size_t)n * c] = pos_tune[r + 3 * c];
+                SQ[3 + r + (size_t)n * (3 + c)] = ori_tune[r + 3 * c];
+            }
+    }
+    if (!dfdx) return;
+    for (size_t i = 0; i < (size_t)n * n; ++i) dfdx[i] = 0.0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            dfdx[6 + r + (size_t)n * c] = Rnc[r + 3 * c];
+            dfdx[9 + r + (size_t)n * (3 + c)] = T[r + 3 * c];
+        }
+    const double x1dot = x[0], x2dot = x[1], x3dot = x[2], thetadot = x[4], psidot = x[5];
+    double d[6][3];                                          /* dfdnu(:, 3..5), src/model.cpp:117-132 */
+    d[0][0] = x2dot * (sin(phi) * sin(psi) + cos(phi) * cos(psi) * sin(theta)) + x3dot * (cos(phi) * sin(psi) - cos(psi) * sin(phi) * sin(theta));
+    d[1][0] = -x2dot * (cos(psi) * sin(phi) - cos(phi) * sin(psi) * sin(theta)) - x3dot * (cos(phi) * cos(psi) + sin(phi) * sin(psi) * sin(theta));
+    d[2][0] = x2dot * cos(phi) * cos(theta) - x3dot * cos(theta) * sin(phi);
+    d[3][0] = thetadot * cos(phi) * tan(theta) - psidot * sin(phi) * tan(theta);
+    d[4][0] = -psidot * cos(phi) - thetadot * sin(phi);
+    d[5][0] = (thetadot * cos(phi)) / cos(theta) - (psidot * sin(phi)) / cos(theta);
+    d[0][1] = x3dot * cos(phi) * cos(psi) * cos(theta) - x1dot * cos(psi) * sin(theta) + x2dot * cos(psi) * cos(theta) * sin(phi);
+    d[1][1] = x3dot * cos(phi) * cos(theta) * sin(psi) - x1dot * sin(psi) * sin(theta) + x2dot * cos(theta) * sin(phi) * sin(psi);
+    d[2][1] = -x1dot * cos(theta) - x3dot * cos(phi) * sin(theta) - x2dot * sin(phi) * sin(theta);
+    d[3][1] = psidot * cos(phi) * (pow(tan(theta), 2) + 1) + thetadot * sin(phi) * (pow(tan(theta), 2) + 1);
+    d[4][1] = 0;
+    d[5][1] = (psidot * cos(phi) * sin(theta)) / pow(cos(theta), 2) + (thetadot * sin(phi) * sin(theta)) / pow(cos(theta), 2);
+    d[0][2] = x3dot * (cos(psi) * sin(phi) - cos(phi) * sin(psi) * sin(theta)) - x2dot * (cos(phi) * cos(psi) + sin(phi) * sin(psi) * sin(theta)) - x1dot * cos(theta) * sin(psi);
+    d[1][2] = x3dot * (sin(phi) * sin(psi) + cos(phi) * cos(psi) * sin(theta)) - x2dot * (cos(phi) * sin(psi) - cos(psi) * sin(phi) * sin(theta)) + x1dot * cos(psi) * cos(theta);
+    d[2][2] = d[3][2] = d[4][2] = d[5][2] = 0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 6; ++r) dfdx[6 + r + (size_t)n * (9 + c)] = d[r][c];
+}
+
+/* augmentGradients, src/gaussian.hpp:140-161: dX = [f(X(:,0)), Jx * X(:,1:)] for X n x (2n+1). */
+static void augment_gradients(const double *X, int n, const double *pos_tune, const double *ori_tune,
+                              double *dX, double *Jx)
+{
+    const int nc = 2 * n + 1;
+    orc_process_model(X, n, pos_tune, ori_tune, dX, NULL, Jx);
+    for (int c = 1; c < nc; ++c) {
+        double *out = dX + (size_t)n * c;
+        const double *xc = X + (size_t)n * c;
+        for (int i = 0; i < n; ++i) out[i] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double xk = xc[k];
+            if (xk == 0.0) continue;                          /* a dense product; zero terms add nothing */
+            const double *jc = Jx + (size_t)n * k;
+            for (int i = 0; i < n; ++i) out[i] += jc[i] * xk;
+        }
+    }
+}
+
+/* RK4SDEHelper, src/gaussian.hpp:171-239.  xdw = [x; dw] (2n).  J (n x 2n column-major) may be NULL. */
+void orc_rk4_sde(const double *xdw, int n, const double *pos_tune, const double *ori_tune, double dt,
+                 double *xnext, double *J)
+{
+    const int nc = 2 * n + 1;
+    const size_t sz = (size_t)n * nc;
+    double *X = (double *)calloc(sz, sizeof(double)), *dW = (double *)calloc(sz, sizeof(double));
+    double *Xs = (double *)malloc(sz * sizeof(double)), *Jx = (double *)malloc((size_t)n * n * sizeof(double));
+    double *F[4];
+    for (int s = 0; s < 4; ++s) F[s] = (double *)malloc(sz * sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        X[i] = xdw[i]; dW[i] = xdw[n + i];
+        X[i + (size_t)n * (1 + i)] = 1.0;
+        dW[i + (size_t)n * (1 + n + i)] = 1.0;
+    }
+    augment_gradients(X, n, pos_tune, ori_tune, F[0], Jx);
+    for (size_t i = 0; i < sz; ++i) Xs[i] = X[i] + (F[0][i] * dt + dW[i]) / 2;
+    augment_gradients(Xs, n, pos_tune, ori_tune, F[1], Jx);
+    for (size_t i = 0; i < sz; ++i) Xs[i] = X[i] + (F[1][i] * dt + dW[i]) / 2;
+    augment_gradients(Xs, n, pos_tune, ori_tune, F[2], Jx);
+    for (size_t i = 0; i < sz; ++i) Xs[i] = X[i] + F[2][i] * dt + dW[i];
+    augment_gradients(Xs, n, pos_tune, ori_tune, F[3], Jx);
+    for (size_t i = 0; i < sz; ++i) Xs[i] = X[i] + (F[0][i] + 2 * F[1][i] + 2 * F[2][i] + F[3][i]) * dt / 6 + dW[i];
+    for (int i = 0; i < n; ++i) xnext[i] = Xs[i];
+    if (J) for (size_t i = 0; i < (size_t)n * 2 * n; ++i) J[i] = Xs[n + i];
+    for (int s = 0; s < 4; ++s) free(F[s]);
+    free(X); free(dW); free(Xs); free(Jx);
+}
+
+/* timeUpdateContinuous, src/gaussian.hpp:337-383, with SlamProcessModel: the augmented state
+ * [x; dw] ~ N([mu; 0], blkdiag(S, SQ sqrt(dt))) goes through affineTransform with the RK4 map. */
+void orc_time_update(const double *mu, const double *S, int n, int ldS, const double *pos_tune,
+                     const double *ori_tune, double dt, double *mu_out, double *S_out, int ldo)
+{
+    const int n2 = 2 * n, rows = 3 * n;
+    double *xdw = (double *)calloc((size_t)n2, sizeof(double));
+    double *f = (double *)malloc(sizeof(double) * (size_t)n), *SQ = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *Sxdw = (double *)calloc((size_t)n2 * n2, sizeof(double));
+    double *J = (double *)malloc(sizeof(double) * (size_t)n * n2);
+    double *A = (double *)calloc((size_t)rows * n, sizeof(double));           /* [Sxdw * J^T ; SR = 0] */
+    for (int i = 0; i < n; ++i) xdw[i] = mu[i];
+    orc_process_model(mu, n, pos_tune, ori_tune, f, SQ, NULL);
+    const double sq = sqrt(dt);
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) {
+            Sxdw[r + (size_t)n2 * c] = S[r + (size_t)ldS * c];
+            Sxdw[n + r + (size_t)n2 * (n + c)] = SQ[r + (size_t)n * c] * sq;
+        }
+    orc_rk4_sde(xdw, n, pos_tune, ori_tune, dt, mu_out, J);
+    for (int c = 0; c < n; ++c) {                                             /* column c of Sxdw * J^T */
+        double *out = A + (size_t)rows * c;
+        for (int k = 0; k < n2; ++k) {
+            const double jk = J[c + (size_t)n * k];
+            if (jk == 0.0) continue;
+            const double *sc = Sxdw + (size_t)n2 * k;
+            for (int i = 0; i < n2; ++i) out[i] += sc[i] * jk;
+        }
+    }
+    orc_qr_upper(A, rows, n, rows);
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) S_out[r + (size_t)ldo * c] = A[r + (size_t)rows * c];
+    free(xdw); free(f); free(SQ); free(Sxdw); free(J); free(A);
+}
+
 /* ================= data association ================= */
 
 /* src/utility.cpp:20-24 */

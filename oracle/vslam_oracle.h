@@ -124,6 +124,20 @@ int orc_measurement_update_iekf(const double *mu, const double *S, int n,
                                 double *mu_post, double *S_post,
                                 int *iters, int *cost_evals);
 
+/* ---- time update ---- */
+/* SlamProcessModel, src/model.cpp:9-136: f (n), SQ (n x n or NULL), dfdx (n x n or NULL);
+ * pos_tune / ori_tune are SlamParameters::position_tune / orientation_tune (3x3 column-major). */
+void orc_process_model(const double *x, int n, const double *pos_tune, const double *ori_tune,
+                       double *f, double *SQ, double *dfdx);
+/* RK4SDEHelper with Jacobian propagation, src/gaussian.hpp:140-239.  xdw = [x; dw] (2n);
+ * xnext (n); J = d xnext / d [x; dw] (n x 2n) or NULL. */
+void orc_rk4_sde(const double *xdw, int n, const double *pos_tune, const double *ori_tune, double dt,
+                 double *xnext, double *J);
+/* timeUpdateContinuous, src/gaussian.hpp:337-383 (dense, the 3n x n Householder QR included).
+ * No reference test holds numbers for it (test/src/kalman.cpp is commented out): parity unpinned. */
+void orc_time_update(const double *mu, const double *S, int n, int ldS, const double *pos_tune,
+                     const double *ori_tune, double dt, double *mu_out, double *S_out, int ldo);
+
 /* ---- data association (src/dataAssociation.cpp, src/utility.cpp) ---- */
 /* normcdf, src/utility.cpp:20-24. */
 double orc_normcdf(double z);

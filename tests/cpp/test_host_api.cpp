@@ -279,6 +279,32 @@ static void test_data_association(const std::string &xml)
     CHECK_TRUE(s < 5 * (std::log(sc.param.camera_param.cam.width) + std::log(sc.param.camera_param.cam.height)));
 }
 
+// The case of test/src/kalman.cpp:11-72 (two landmarks, diagonal factor, timestep 0.01): output shapes
+// equal input shapes; in addition the velocity and landmark means do not move and the first
+// column's norm is the propagated variance of the first state.
+static void test_time_update()
+{
+    const int n = 18;
+    Vector mu(n), u, mup;
+    Matrix S(n, n), Sp;
+    for (int i = 0; i < n; ++i) { mu(i) = 0.1 * (i + 1); S(i, i) = i + 1; }
+    SlamParameters p;
+    p.position_tune(0, 0) = 0.5; p.position_tune(1, 1) = 0.5; p.position_tune(2, 2) = 0.175;
+    p.orientation_tune(0, 0) = p.orientation_tune(1, 1) = p.orientation_tune(2, 2) = 0.05;
+    SlamProcessModel pm;
+    const double timestep = 0.01;
+    timeUpdateContinuous(mu, S, u, pm, p, timestep, mup, Sp);
+    CHECK_TRUE(mup.rows() == mu.rows() && mup.cols() == mu.cols());
+    CHECK_TRUE(Sp.rows() == S.rows() && Sp.cols() == S.cols());
+    for (int i = 0; i < 6; ++i) CHECK_NEAR(mup(i), mu(i), 0.0);
+    for (int i = 12; i < n; ++i) CHECK_NEAR(mup(i), mu(i), 0.0);
+    CHECK_TRUE(std::fabs(mup(6) - mu(6)) > 1e-6);                       // the camera moved
+    CHECK_NEAR(Sp(0, 0) * Sp(0, 0), 1.0 + timestep * 0.25, 1e-13);
+    for (int j = 0; j < n; ++j)
+        for (int i = j + 1; i < n; ++i) CHECK_TRUE(Sp(i, j) == 0.0);
+    for (int j = 12; j < n; ++j) CHECK_NEAR(std::fabs(Sp(j, j)), j + 1.0, 1e-13);   // landmarks: no process noise
+}
+
 static void test_detect_corners()
 {
     const int w = 320, h = 240;
@@ -308,6 +334,7 @@ int main(int argc, char **argv)
         test_measurement_update(argv[1]);
         test_detect_corners();
         test_data_association(argv[1]);
+        test_time_update();
         // Contract violations surface as exceptions carrying the library's message, not aborts.
         bool threw = false;
         try {

@@ -1,0 +1,100 @@
+"""GPU parity of the time update (vslam_time_update*) against the CPU oracle's dense restatement of
+timeUpdateContinuous (reference src/gaussian.hpp:337-383).  The device path works on the 12-state
+RK4 block and an (n + 6) x n QR; the oracle does the reference's full n x (2n + 1) recursion and the
+3n x n QR.  Tolerance: 1e-9 relative (fp64).  Parity with the reference itself is unpinned: it has no
+test with numbers for this step."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+PT = np.diag([0.5, 0.5, 0.175])
+OT = np.diag([0.05, 0.05, 0.05])
+TOL = 1e-9
+
+
+def _filter(L, seed):
+    from visualslam_amd import synthetic as syn
+    sc = syn.Scene(L, seed)
+    rng = np.random.default_rng(seed + 77)
+    x = sc.x.copy()
+    x[:6] = 0.2 * rng.standard_normal(6)               # moving camera
+    return x, sc.S
+
+
+@pytest.mark.parametrize("L,seed,dt", [(1, 5, 0.02), (2, 6, 1 / 30), (50, 1023, 1 / 30), (150, 3, 0.05)])
+def test_time_update_matches_oracle(ctx, L, seed, dt):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    x, S = _filter(L, seed)
+    mu0, S0 = orc.time_update(x, S, PT, OT, dt)
+    mu1, S1 = api.time_update(ctx, x, S, PT, OT, dt)
+    assert rel_err(mu1, mu0) < TOL
+    assert rel_err(S1, S0) < TOL
+    assert not np.tril(S1, -1).any()
+
+
+def test_no_landmarks_and_full_tuning_matrices(ctx):
+    """n = 12 (no landmarks) and non-diagonal tuning matrices."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(9)
+    x = 0.3 * rng.standard_normal(12)
+    S = np.triu(0.1 * rng.standard_normal((12, 12))) + 0.3 * np.eye(12)
+    pt, ot = 0.2 * rng.standard_normal((3, 3)), 0.1 * rng.standard_normal((3, 3))
+    mu0, S0 = orc.time_update(x, S, pt, ot, 0.04)
+    mu1, S1 = api.time_update(ctx, x, S, pt, ot, 0.04)
+    assert rel_err(mu1, mu0) < TOL and rel_err(S1, S0) < TOL
+
+
+def test_general_square_factor(ctx):
+    """The reference does not require S to be triangular; neither does the device path."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(10)
+    n = 27
+    x = 0.3 * rng.standard_normal(n)
+    S = 0.1 * rng.standard_normal((n, n)) + 0.3 * np.eye(n)
+    mu0, S0 = orc.time_update(x, S, PT, OT, 0.03)
+    mu1, S1 = api.time_update(ctx, x, S, PT, OT, 0.03)
+    assert rel_err(mu1, mu0) < TOL and rel_err(S1, S0) < TOL
+
+
+def test_zero_timestep_keeps_the_covariance(ctx):
+    """dt = 0: the mean does not move and S'S is unchanged (R of qr(S) has the rows of S up to sign)."""
+    from visualslam_amd import api
+    x, S = _filter(20, 11)
+    mu1, S1 = api.time_update(ctx, x, S, PT, OT, 0.0)
+    assert np.array_equal(mu1, x)
+    assert rel_err(S1.T @ S1, S.T @ S) < 1e-12
+
+
+def test_errors(ctx):
+    from visualslam_amd import api
+    with pytest.raises(api.VslamError):
+        api.time_update(ctx, np.zeros(11), np.eye(11), PT, OT, 0.1)
+    with pytest.raises(api.VslamError):
+        api.time_update(ctx, np.zeros(15), np.eye(15), PT, OT, -1.0)
+
+
+def test_batch_dev_in_place(ctx):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    B, L = 12, 10
+    n = 12 + 3 * L
+    xs, Ss = zip(*[_filter(L, 200 + b) for b in range(B)])
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(np.stack(xs), device=dev)
+    S = torch.tensor(np.stack([s.T for s in Ss]).copy(), device=dev)          # column-major per instance
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    api.time_update_batch_dev(tctx, mu, S, n, PT, OT, 0.04, mu, S)
+    torch.cuda.synchronize()
+    mu_h, S_h = mu.cpu().numpy(), S.cpu().numpy()
+    for b in range(B):
+        mu0, S0 = orc.time_update(xs[b], Ss[b], PT, OT, 0.04)
+        assert rel_err(mu_h[b], mu0) < TOL
+        assert rel_err(S_h[b].T, S0) < TOL
+    tctx.close()

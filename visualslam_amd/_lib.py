@@ -107,6 +107,8 @@ def _declare(L):
         "vslam_snn_density": [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp],
         "vslam_snn_density_batch_dev": [_vp, _i, _vp, _sz, _vp, _i, _sz, _i, _vp, _sz, _i, _i, _i, _i, _vp, _vp],
         "vslam_snn": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+        "vslam_time_update": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _i],
+        "vslam_time_update_batch_dev": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp],
         "vslam_corner_detect": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
         "vslam_corner_response": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _vp, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],

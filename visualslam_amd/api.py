@@ -191,6 +191,16 @@ def condition_on_marginal(ctx, muyx, Syx, y):
     return mu, Sx
 
 
+def time_update(ctx, mu, S, pos_tune, ori_tune, dt):
+    """timeUpdateContinuous with SlamProcessModel (reference src/gaussian.hpp:337-383): returns (mu+, S+)."""
+    mu, S, pt, ot = _f64(mu), _F(S), _F(pos_tune), _F(ori_tune)
+    n = mu.size
+    mup = np.zeros(n)
+    Sp = np.zeros((n, n), order="F")
+    check(ctx._L.vslam_time_update(ctx.ptr, _p(mu), _p(S), n, n, _p(pt), _p(ot), float(dt), _p(mup), _p(Sp), n), ctx.ptr)
+    return mup, Sp
+
+
 def cost_joint_density(ctx, cam, x, mu, S, y, visible, sigma):
     x, mu, S, y = _f64(x), _f64(mu), _F(S), _f64(y)
     n = x.size
@@ -306,6 +316,13 @@ def snn_density_batch_dev(ctx, muY, SYY, y, n, m, width, height, idx, surprisal,
     B, N = muY.shape[0], 2 * n
     check(ctx._L.vslam_snn_density_batch_dev(ctx.ptr, B, _tp(muY), N, _tp(SYY), N, N * N, n, _tp(y), 2 * m, m, int(width),
                                              int(height), int(enforce_jc), _tp(idx), _tp(surprisal)), ctx.ptr)
+
+
+def time_update_batch_dev(ctx, mu, S, n, pos_tune, ori_tune, dt, mu_out, S_out):
+    """torch tensors on the GPU: mu (B, n) f64, S (B, n, n) column-major per instance; outputs alike (may alias)."""
+    pt, ot = _F(pos_tune), _F(ori_tune)
+    check(ctx._L.vslam_time_update_batch_dev(ctx.ptr, _tp(mu), _tp(S), n, mu.shape[0], _p(pt), _p(ot), float(dt),
+                                             _tp(mu_out), _tp(S_out)), ctx.ptr)
 
 
 def corner_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, params, detector, out, cap, count):

@@ -9,6 +9,7 @@
 //   logGaussian, affineTransform,
 //   measurementUpdateIEKF                         src/gaussian.hpp:30-131,469-532
 //   conditionGaussianOnMarginal                   src/gaussian.cpp:19-36
+//   SlamProcessModel, timeUpdateContinuous        src/model.hpp:36-41, src/gaussian.hpp:337-383
 //   Feature, detectCorners                        src/imagefeatures.h:15-19,37
 //   chi2inv, normcdf                              src/utility.cpp:13-24
 //   individualCompatibility, jointCompatibility,
@@ -153,6 +154,8 @@ struct SlamParameters {
     CameraParameters camera_param;
     double measurement_noise = 7.0;
     std::vector<Landmark> landmarks;
+    Matrix position_tune{3, 3};        // process noise factors (src/model.hpp:17-18)
+    Matrix orientation_tune{3, 3};
 };
 
 namespace detail {
@@ -263,6 +266,20 @@ int measurementUpdateIEKF(const Vec &mux, const Mat &Sxx, const Vec &, const Vec
     check(vslam_measurement_update_iekf(context(), &param.camera_param.cam, mux.data(), Sxx.data(), n, (int)Sxx.rows(), y.data(), vis.data(),
                                         param.measurement_noise, muxGy.data(), SxxGy.data(), n, &code, nullptr, nullptr));
     return code;
+}
+
+// timeUpdateContinuous(mukm1, Skm1, u, SlamProcessModel, param, timestep, muk, Sk), src/gaussian.hpp:337-383
+// as called at src/SLAM.cpp:250,337,507.  u is unused, as in the reference's process model.
+struct SlamProcessModel {};
+template <class Vec, class Mat>
+void timeUpdateContinuous(const Vec &mukm1, const Mat &Skm1, const Vec &, SlamProcessModel, const SlamParameters &param, double timestep,
+                          Vec &muk, Mat &Sk)
+{
+    const int n = (int)mukm1.size();
+    if (n <= 0 || Skm1.rows() != n || Skm1.cols() != n) throw std::runtime_error("timeUpdateContinuous: bad input shapes");
+    muk.resize(n, 1); Sk.resize(n, n);
+    check(vslam_time_update(context(), mukm1.data(), Skm1.data(), n, n, param.position_tune.data(), param.orientation_tune.data(),
+                            timestep, muk.data(), Sk.data(), n));
 }
 
 // Opt-in: solve the trust-region subproblems of measurementUpdateIEKF on the device from Cholesky
