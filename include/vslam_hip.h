@@ -235,6 +235,27 @@ vslam_status vslam_time_update_batch_dev(vslam_ctx *ctx, const double *mu, const
                                          const double *pos_tune, const double *ori_tune, double dt,
                                          double *mu_out, double *S_out);
 
+/* ---- landmark removal ----
+ * removeBadLandmarks(mup, Sp, landmarks, j), src/SLAM.cpp:796-820: the three states of landmark j leave
+ * mu (rows 12+3j..14+3j) and S (the same columns, src/SLAM.cpp:848-868); the n x (n-3) factor is
+ * re-triangularised by Householder QR and its leading (n-3) x (n-3) block returned. */
+vslam_status vslam_remove_landmark(vslam_ctx *ctx, const double *mu, const double *S, int n, int ldS, int j,
+                                   double *mu_out, double *S_out, int ldSout);
+
+/* ---- descriptor matching ----
+ * cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches), src/SLAM.cpp:222,355: for each of the
+ * nq query descriptors (rows of desc_bytes bytes; 32 for ORB) the index of the train descriptor at the
+ * smallest Hamming distance -- the lowest index among equals -- and that distance (may be NULL).
+ * nt == 0 gives index and distance -1 (OpenCV returns no match). */
+vslam_status vslam_match_hamming(vslam_ctx *ctx, const uint8_t *query, int nq, const uint8_t *train, int nt,
+                                 int desc_bytes, int32_t *train_idx, int32_t *distance);
+/* Device-pointer batch: instance b reads query + b*stride_query, train + b*stride_train (byte strides,
+ * multiples of 4; 16-byte aligned train sets take the fast path), writes train_idx + b*nq.  nt_each
+ * (device, may be NULL) gives the number of valid train descriptors of each instance (<= nt). */
+vslam_status vslam_match_hamming_batch_dev(vslam_ctx *ctx, const uint8_t *query, size_t stride_query, int nq,
+                                           const uint8_t *train, size_t stride_train, int nt, const int32_t *nt_each,
+                                           int desc_bytes, int batch, int32_t *train_idx, int32_t *distance);
+
 /* ---- corner front end ----
  * The feature stage of detectAndDrawORB, src/imagefeatures.cpp:71-96, reduced
  * to what the caller consumes (src/SLAM.cpp:449-472): keypoints with a

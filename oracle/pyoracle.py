@@ -280,6 +280,25 @@ def time_update(mu, S, pos_tune, ori_tune, dt):
     return mup, Sp
 
 
+def remove_landmark(mu, S, j):
+    mu, S = _f64(mu), _F(S)
+    n = mu.size
+    mo = np.zeros(n - 3)
+    So = np.zeros((n - 3, n - 3), order="F")
+    _lib.orc_remove_landmark(_d(mu), _d(S), n, n, int(j), _d(mo), _d(So), n - 3)
+    return mo, So
+
+
+def match_hamming(query, train):
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    train = np.ascontiguousarray(train, dtype=np.uint8).reshape(-1, query.shape[1])
+    nq, nb = query.shape
+    idx = np.zeros(nq, np.int32)
+    dist = np.zeros(nq, np.int32)
+    _lib.orc_match_hamming(_b(query), nq, _b(train), train.shape[0], nb, _i(idx), _i(dist))
+    return idx, dist
+
+
 def corner_params(block_size=7, border=None, max_features=10000, harris_k=0.04,
                   harris_thresh=1e-4, shi_thresh=1e-3):
     p = CornerParams()

@@ -851,6 +851,39 @@ void orc_time_update(const double *mu, const double *S, int n, int ldS, const do
     free(xdw); free(f); free(SQ); free(Sxdw); free(J); free(A);
 }
 
+/* removeBadLandmarks, src/SLAM.cpp:796-820 (removeRow / removeColumn :848-868). */
+void orc_remove_landmark(const double *mu, const double *S, int n, int ldS, int j, double *mu_out,
+                         double *S_out, int ldo)
+{
+    const int c0 = 12 + 3 * j, m = n - 3;
+    double *A = (double *)malloc(sizeof(double) * (size_t)n * m);
+    for (int i = 0; i < m; ++i) mu_out[i] = mu[i < c0 ? i : i + 3];
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < n; ++r) A[r + (size_t)n * c] = S[r + (size_t)ldS * (c < c0 ? c : c + 3)];
+    orc_qr_upper(A, n, m, n);
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) S_out[r + (size_t)ldo * c] = A[r + (size_t)n * c];
+    free(A);
+}
+
+/* cv::BFMatcher(NORM_HAMMING).match(query, train), src/SLAM.cpp:222,355: nearest train descriptor per
+ * query, first index among equal distances; -1 when there is no train descriptor.  OpenCV's matcher
+ * is not in this environment: this restates its documented behaviour (parity unpinned). */
+void orc_match_hamming(const uint8_t *query, int nq, const uint8_t *train, int nt, int desc_bytes,
+                       int32_t *train_idx, int32_t *distance)
+{
+    for (int q = 0; q < nq; ++q) {
+        int best = -1, bi = -1;
+        for (int t = 0; t < nt; ++t) {
+            int d = 0;
+            for (int b = 0; b < desc_bytes; ++b) d += __builtin_popcount((unsigned)(query[(size_t)q * desc_bytes + b] ^ train[(size_t)t * desc_bytes + b]));
+            if (bi < 0 || d < best) { best = d; bi = t; }
+        }
+        train_idx[q] = bi;
+        if (distance) distance[q] = best;
+    }
+}
+
 /* ================= data association ================= */
 
 /* src/utility.cpp:20-24 */

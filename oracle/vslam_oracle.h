@@ -138,6 +138,13 @@ void orc_rk4_sde(const double *xdw, int n, const double *pos_tune, const double 
 void orc_time_update(const double *mu, const double *S, int n, int ldS, const double *pos_tune,
                      const double *ori_tune, double dt, double *mu_out, double *S_out, int ldo);
 
+/* removeBadLandmarks, src/SLAM.cpp:796-820: mu_out (n-3), S_out ((n-3) x (n-3), ld ldo). */
+void orc_remove_landmark(const double *mu, const double *S, int n, int ldS, int j, double *mu_out,
+                         double *S_out, int ldo);
+/* cv::BFMatcher(NORM_HAMMING).match, src/SLAM.cpp:222,355 (first nearest train descriptor per query). */
+void orc_match_hamming(const uint8_t *query, int nq, const uint8_t *train, int nt, int desc_bytes,
+                       int32_t *train_idx, int32_t *distance);
+
 /* ---- data association (src/dataAssociation.cpp, src/utility.cpp) ---- */
 /* normcdf, src/utility.cpp:20-24. */
 double orc_normcdf(double z);

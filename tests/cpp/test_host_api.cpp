@@ -305,6 +305,40 @@ static void test_time_update()
     for (int j = 12; j < n; ++j) CHECK_NEAR(std::fabs(Sp(j, j)), j + 1.0, 1e-13);   // landmarks: no process noise
 }
 
+// removeBadLandmarks (src/SLAM.cpp:796-820) and the descriptor matcher (src/SLAM.cpp:355).
+static void test_landmark_bookkeeping()
+{
+    const int n = 21;
+    Vector mu(n);
+    Matrix S(n, n);
+    std::mt19937 gen(11);
+    std::normal_distribution<double> nd;
+    for (int j = 0; j < n; ++j) { mu(j) = j; for (int i = 0; i <= j; ++i) S(i, j) = nd(gen); }
+    std::vector<Landmark> lms(3);
+    Vector mu2 = mu; Matrix S2 = S;
+    removeBadLandmarks(mu2, S2, lms, 1);
+    CHECK_TRUE(lms.size() == 2 && mu2.rows() == n - 3 && S2.rows() == n - 3 && S2.cols() == n - 3);
+    for (int i = 0; i < n - 3; ++i) CHECK_NEAR(mu2(i), i < 15 ? i : i + 3, 0.0);
+    // S2' S2 equals the marginal of S' S
+    for (int a = 0; a < n - 3; a += 4)
+        for (int b = 0; b < n - 3; b += 3) {
+            const int ia = a < 15 ? a : a + 3, ib = b < 15 ? b : b + 3;
+            double got = 0.0, want = 0.0;
+            for (int k = 0; k < n - 3; ++k) got += S2(k, a) * S2(k, b);
+            for (int k = 0; k < n; ++k) want += S(k, ia) * S(k, ib);
+            CHECK_NEAR(got, want, 1e-12);
+        }
+    std::vector<uint8_t> train(64 * 32), query(2 * 32);
+    for (size_t i = 0; i < train.size(); ++i) train[i] = (uint8_t)(gen() & 0xFF);
+    for (int b = 0; b < 32; ++b) { query[(size_t)b] = train[(size_t)(40 * 32 + b)]; query[(size_t)(32 + b)] = train[(size_t)(7 * 32 + b)]; }
+    query[0] ^= 0x11;                                  // two bits away from train row 40
+    std::vector<Match> matches;
+    matchHamming(query.data(), 2, train.data(), 64, 32, matches);
+    CHECK_TRUE(matches.size() == 2);
+    CHECK_TRUE(matches[0].trainIdx == 40 && matches[0].distance == 2.0f && matches[0].queryIdx == 0);
+    CHECK_TRUE(matches[1].trainIdx == 7 && matches[1].distance == 0.0f);
+}
+
 static void test_detect_corners()
 {
     const int w = 320, h = 240;
@@ -335,6 +369,7 @@ int main(int argc, char **argv)
         test_detect_corners();
         test_data_association(argv[1]);
         test_time_update();
+        test_landmark_bookkeeping();
         // Contract violations surface as exceptions carrying the library's message, not aborts.
         bool threw = false;
         try {

@@ -86,3 +86,29 @@ def test_kalman_case_dimensions():
     assert mup.shape == mu.shape and Sp.shape == S.shape
     assert np.array_equal(mup[12:], mu[12:]) and np.array_equal(mup[:6], mu[:6])
     assert np.all(np.isfinite(Sp))
+
+
+def test_remove_landmark_keeps_the_marginal():
+    """removeBadLandmarks (src/SLAM.cpp:796-820): mean rows / factor columns 12+3j.. leave; R'R is the marginal."""
+    rng = np.random.default_rng(5)
+    n, j = 24, 2
+    mu = rng.standard_normal(n)
+    S = np.triu(rng.standard_normal((n, n)))
+    mo, So = orc.remove_landmark(mu, S, j)
+    keep = [i for i in range(n) if not 18 <= i < 21]
+    assert np.array_equal(mo, mu[keep])
+    assert np.abs(So.T @ So - (S.T @ S)[np.ix_(keep, keep)]).max() < 1e-12
+    assert np.abs(So - np.linalg.qr(S[:, keep], mode="r")).max() < 1e-12       # LAPACK's signs
+
+
+def test_match_hamming_against_numpy():
+    rng = np.random.default_rng(6)
+    q = rng.integers(0, 256, (17, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (301, 32), dtype=np.uint8)
+    t[200] = q[3]; t[250] = q[3]                     # two exact copies: the first wins
+    idx, dist = orc.match_hamming(q, t)
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(idx, d.argmin(axis=1)) and np.array_equal(dist, d.min(axis=1))
+    assert idx[3] == 200 and dist[3] == 0
+    idx, dist = orc.match_hamming(q, np.zeros((0, 32), np.uint8))
+    assert np.all(idx == -1)

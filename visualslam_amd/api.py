@@ -201,6 +201,27 @@ def time_update(ctx, mu, S, pos_tune, ori_tune, dt):
     return mup, Sp
 
 
+def remove_landmark(ctx, mu, S, j):
+    """removeBadLandmarks (reference src/SLAM.cpp:796-820): returns (mu, S) without landmark j."""
+    mu, S = _f64(mu), _F(S)
+    n = mu.size
+    mo = np.zeros(max(n - 3, 0))
+    So = np.zeros((max(n - 3, 0), max(n - 3, 0)), order="F")
+    check(ctx._L.vslam_remove_landmark(ctx.ptr, _p(mu), _p(S), n, n, int(j), _p(mo), _p(So), max(n - 3, 1)), ctx.ptr)
+    return mo, So
+
+
+def match_hamming(ctx, query, train):
+    """cv::BFMatcher(NORM_HAMMING).match (reference src/SLAM.cpp:355): (train_idx, distance) per query row."""
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    nq, nb = query.shape
+    train = np.ascontiguousarray(train, dtype=np.uint8).reshape(-1, nb)
+    idx = np.zeros(nq, np.int32)
+    dist = np.zeros(nq, np.int32)
+    check(ctx._L.vslam_match_hamming(ctx.ptr, _p(query), nq, _p(train), train.shape[0], nb, _p(idx), _p(dist)), ctx.ptr)
+    return idx, dist
+
+
 def cost_joint_density(ctx, cam, x, mu, S, y, visible, sigma):
     x, mu, S, y = _f64(x), _f64(mu), _F(S), _f64(y)
     n = x.size
@@ -323,6 +344,15 @@ def time_update_batch_dev(ctx, mu, S, n, pos_tune, ori_tune, dt, mu_out, S_out):
     pt, ot = _F(pos_tune), _F(ori_tune)
     check(ctx._L.vslam_time_update_batch_dev(ctx.ptr, _tp(mu), _tp(S), n, mu.shape[0], _p(pt), _p(ot), float(dt),
                                              _tp(mu_out), _tp(S_out)), ctx.ptr)
+
+
+def match_hamming_batch_dev(ctx, query, train, idx, dist=None, nt_each=None):
+    """torch u8 tensors on the GPU: query (B, nq, bytes), train (B, nt, bytes); idx/dist (B, nq) int32."""
+    B, nq, nb = query.shape
+    nt = train.shape[1]
+    check(ctx._L.vslam_match_hamming_batch_dev(ctx.ptr, _tp(query), nq * nb, nq, _tp(train), nt * nb, nt,
+                                               _tp(nt_each) if nt_each is not None else None, nb, B, _tp(idx),
+                                               _tp(dist) if dist is not None else None), ctx.ptr)
 
 
 def corner_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, params, detector, out, cap, count):

@@ -10,6 +10,7 @@
 //   measurementUpdateIEKF                         src/gaussian.hpp:30-131,469-532
 //   conditionGaussianOnMarginal                   src/gaussian.cpp:19-36
 //   SlamProcessModel, timeUpdateContinuous        src/model.hpp:36-41, src/gaussian.hpp:337-383
+//   removeBadLandmarks, matchHamming (BFMatcher)  src/SLAM.cpp:796-820, 222,355
 //   Feature, detectCorners                        src/imagefeatures.h:15-19,37
 //   chi2inv, normcdf                              src/utility.cpp:13-24
 //   individualCompatibility, jointCompatibility,
@@ -280,6 +281,31 @@ void timeUpdateContinuous(const Vec &mukm1, const Mat &Skm1, const Vec &, SlamPr
     muk.resize(n, 1); Sk.resize(n, n);
     check(vslam_time_update(context(), mukm1.data(), Skm1.data(), n, n, param.position_tune.data(), param.orientation_tune.data(),
                             timestep, muk.data(), Sk.data(), n));
+}
+
+// removeBadLandmarks(mup, Sp, landmarks, j), src/SLAM.cpp:796-820: landmark j leaves the list, the mean and the factor.
+template <class Vec, class Mat, class LandmarkT>
+void removeBadLandmarks(Vec &mup, Mat &Sp, std::vector<LandmarkT> &landmarks, int j)
+{
+    const int n = (int)mup.size();
+    Vec mu_in = mup;
+    Mat S_in = Sp;
+    if (j < 0 || j >= (int)landmarks.size()) throw std::runtime_error("removeBadLandmarks: bad landmark index");
+    landmarks.erase(landmarks.begin() + j);
+    mup.resize(n - 3, 1); Sp.resize(n - 3, n - 3);
+    check(vslam_remove_landmark(context(), mu_in.data(), S_in.data(), n, (int)S_in.rows(), j, mup.data(), Sp.data(), n - 3));
+}
+
+// cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches), src/SLAM.cpp:222,355, on row-major
+// descriptor arrays: the train index (and distance) of the nearest descriptor for every query row.
+struct Match { int queryIdx, trainIdx; float distance; };       // the fields of cv::DMatch the caller reads
+inline void matchHamming(const uint8_t *query, int nq, const uint8_t *train, int nt, int desc_bytes, std::vector<Match> &matches)
+{
+    std::vector<int32_t> idx((size_t)nq), dist((size_t)nq);
+    check(vslam_match_hamming(context(), query, nq, train, nt, desc_bytes, idx.data(), dist.data()));
+    matches.clear();
+    for (int q = 0; q < nq; ++q)
+        if (idx[(size_t)q] >= 0) matches.push_back(Match{q, idx[(size_t)q], (float)dist[(size_t)q]});
 }
 
 // Opt-in: solve the trust-region subproblems of measurementUpdateIEKF on the device from Cholesky
