@@ -200,9 +200,9 @@ struct CoopPanelArgs {
     int ldv, vzero;       // leading dimension; rows above the panel to clear in these columns
 };
 
-__device__ __forceinline__ size_t coop_lds_doubles(int rows_per)
+static size_t coop_lds_bytes(int rows_per)
 {
-    return (size_t)rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4;
+    return ((size_t)rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4) * 8;
 }
 
 __device__ __forceinline__ double coop_poll(const double *p, int *err, bool &dead)
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
     const int r0 = g * a.rows_per;
     const int nr = min(a.rows_per, a.mp - r0);         // >= 1 by construction of G
     const int jb = a.jb, G = a.G;
+    const bool solo = (G == 1);                        // the whole panel is here: no exchange, sums stay in LDS
     bool dead = false;
 
     for (int idx = tid; idx < nr * NB; idx += CP_T) {
@@ -274,11 +275,21 @@ __global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
             if ((tid & 32) == 0) red[(tid >> 6) * NB + k] = s;
     }
     __syncthreads();
-    publish(0);
+    if (!solo) publish(0);
 
     for (int c = 0; c < jb; ++c) {
         const unsigned t = a.tbase + (unsigned)c;
         const double *cur = slots + (size_t)(t % 3) * CP_GMAX * CP_SLOT;
+        if (solo) {
+            if (tid < NB) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < CP_NG / 2; ++q) s += red[q * NB + tid];
+                tot[tid] = s;
+                rc[tid] = P[c * CP_LD + tid];
+            }
+            // tot / rc are written and next read by the same half-wave: no workgroup barrier needed
+        } else {
         // every workgroup adds the partials in the same order
         {
             double v[(CP_GMAX + CP_NG - 1) / CP_NG];
@@ -306,8 +317,11 @@ __global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
             for (int q = 0; q < CP_NG / 2; ++q) s += red[q * NB + tid];
             tot[tid] = s;
         }
-        __syncthreads();
-        if (tid == 0) {
+        }
+        // tot / rc were written by lanes 0..31 of wave 0, the only readers until the next barrier
+        // lanes 0..31 of wave 0: reflector scalars (each lane the same), (V^T v_c)_k for k < c into the
+        // inverse-T form, update weights w_k = tau * v_c^T a_k for k > c
+        if (tid < NB) {
             const double alpha = rc[c], tail = tot[c];
             double beta, tau, scale;
             if (tail <= 2.2250738585072014e-308) { beta = alpha; tau = 0.0; scale = 0.0; }
@@ -317,25 +331,20 @@ __global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
                 scale = 1.0 / (alpha - beta);
                 tau = (beta - alpha) / beta;
             }
-            sc[0] = tau; sc[1] = scale; sc[2] = beta;
-        }
-        __syncthreads();
-        const double tau = sc[0], scale = sc[1], beta = sc[2];
-        // (V^T v_c)_k for k < c goes to the inverse-T form; w_k = tau * v_c^T a_k for k > c
-        if (tid < NB) {
             const double vta = rc[tid] + scale * tot[tid];
             if (tid < c) Ms[tid * (NB + 1) + c] = vta;
             if (tid == c) Ms[c * (NB + 1) + NB] = tau;      // taus live in the pad column
             w[tid] = (tid > c && tid < jb) ? tau * vta : 0.0;
+            if (tid == 0) { sc[0] = tau; sc[1] = scale; sc[2] = beta; }
         }
         __syncthreads();
+        const double scale = sc[1], beta = sc[2];
+        const int c1 = (c + 1 < NB) ? c + 1 : c;       // column whose dots are accumulated (unused when c+1 == jb)
+        const double wk = w[k], wc1 = w[c1];
         // one pass over this workgroup's rows >= c: apply reflector c, accumulate the
         // dot products of the tail (rows > c+1) of the updated column c+1 with every column
         double s = 0.0;
         {
-            const double wk = w[k];
-            const int c1 = (c + 1 < NB) ? c + 1 : c;   // column whose dots are accumulated (unused when c+1 == jb)
-            const double wc1 = w[c1];
             const int lo = max(c - r0, 0);
             for (int li0 = lo + grp; li0 < nr; li0 += 4 * CP_NG) {
                 double xc[4], x1[4], xk[4];
@@ -362,24 +371,27 @@ __global__ __launch_bounds__(CP_T) void qr_panel_coop_kernel(CoopPanelArgs a)
             s += __shfl_xor(s, 32, 64);
             if ((tid & 32) == 0) red[(tid >> 6) * NB + k] = s;
             __syncthreads();
-            publish(c + 1);
+            if (!solo) publish(c + 1);
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < nr * jb; idx += CP_T) {
-        const int li = idx % nr, kk = idx / nr;
-        A[(size_t)kk * a.lda + r0 + li] = P[li * CP_LD + kk];
-    }
-    if (a.V) {
-        for (int idx = tid; idx < nr * jb; idx += CP_T) {
-            const int li = idx % nr, kk = idx / nr, i = r0 + li;
-            a.V[(size_t)kk * a.ldv + i] = (i < kk) ? 0.0 : ((i == kk) ? 1.0 : P[li * CP_LD + kk]);
+    // waves 1.. write the panel back while wave 0 (of workgroup 0) builds T below
+    if (tid >= 64) {
+        for (int idx = tid - 64; idx < nr * jb; idx += CP_T - 64) {
+            const int li = idx % nr, kk = idx / nr;
+            A[(size_t)kk * a.lda + r0 + li] = P[li * CP_LD + kk];
         }
-        if (g == 0)
-            for (int idx = tid; idx < a.vzero * jb; idx += CP_T) {
-                const int z = idx % a.vzero, kk = idx / a.vzero;
-                a.V[(ptrdiff_t)kk * a.ldv - 1 - z] = 0.0;
+        if (a.V) {
+            for (int idx = tid - 64; idx < nr * jb; idx += CP_T - 64) {
+                const int li = idx % nr, kk = idx / nr, i = r0 + li;
+                a.V[(size_t)kk * a.ldv + i] = (i < kk) ? 0.0 : ((i == kk) ? 1.0 : P[li * CP_LD + kk]);
             }
+            if (g == 0)
+                for (int idx = tid - 64; idx < a.vzero * jb; idx += CP_T - 64) {
+                    const int z = idx % a.vzero, kk = idx / a.vzero;
+                    a.V[(ptrdiff_t)kk * a.ldv - 1 - z] = 0.0;
+                }
+        }
     }
     // T = (striu(V^T V) + diag(1/tau))^-1: lane j back-substitutes column j (a reflector with
     // tau = 0 gives a zero row and column).
@@ -583,13 +595,15 @@ static vslam_status qr_factor_panel(QrJob &q, int j, int jb, double *Tdst, doubl
     const int mp = q.rows - j;
     double *P = q.A + (size_t)j * q.lda + j;
     hipStream_t s = q.ctx->stream;
-    if (q.rows_per > 0) {
+    if (q.rows_per > 0 || mp <= CP_RMAX) {
+        // A panel of at most CP_RMAX rows fits one workgroup's LDS: no exchange, any batch.
+        const int rows_per = (mp <= CP_RMAX) ? ((mp + 63) / 64) * 64 : q.rows_per;
         CoopPanelArgs ca;
-        ca.A = P; ca.lda = q.lda; ca.strideA = q.strideA; ca.mp = mp; ca.jb = jb; ca.rows_per = q.rows_per;
-        ca.G = (mp + q.rows_per - 1) / q.rows_per; ca.tbase = q.tbase;
+        ca.A = P; ca.lda = q.lda; ca.strideA = q.strideA; ca.mp = mp; ca.jb = jb; ca.rows_per = rows_per;
+        ca.G = (mp + rows_per - 1) / rows_per; ca.tbase = q.tbase;
         ca.M = Tdst; ca.slots = q.w.slots; ca.err = q.ctx->flags;
         ca.V = Vout; ca.ldv = ldv; ca.vzero = vzero;
-        const size_t lds = ((size_t)q.rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4) * 8;
+        const size_t lds = coop_lds_bytes(rows_per);
         hipLaunchKernelGGL(qr_panel_coop_kernel, dim3(ca.G, q.batch), dim3(CP_T), lds, s, ca);
         q.tbase += (unsigned)jb;
     } else {
@@ -724,7 +738,10 @@ vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda
     if (q.rows_per > 0) {
         const size_t words = (size_t)batch * 3 * CP_GMAX * CP_SLOT * 2;
         VSLAM_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q.w.slots), (int)CP_EMPTY32, words, s));
-        const size_t lds = ((size_t)q.rows_per * CP_LD + CP_NG * NB + 3 * NB + NB * (NB + 1) + 4) * 8;
+    }
+    {
+        const int solo_rows = ((((rows < CP_RMAX) ? rows : CP_RMAX) + 63) / 64) * 64;   // largest single-workgroup panel
+        const size_t lds = coop_lds_bytes(solo_rows > q.rows_per ? solo_rows : q.rows_per);
         if (lds > 48 * 1024)
             VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&qr_panel_coop_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
