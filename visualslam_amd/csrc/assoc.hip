@@ -38,6 +38,7 @@ struct AssocArgs {
     int32_t *jc_out;                     // [batch] (mode 1) joint compatibility
     double *ws; size_t s_ws;             // per instance: V[N*N] T[N*N] z[N] a[2N] b[2N] w[2N] u[2N] t[2N]
     uint8_t *avail; size_t s_av;         // [m]
+    int vec_lds;                         // work vectors in LDS instead of ws (set by assoc_launch)
 };
 
 __device__ __forceinline__ double wg_sum(double v, double *red)
@@ -87,6 +88,41 @@ __device__ void apply_reflector(const double *x, double tau, int k0, int N, doub
     __syncthreads();
 }
 
+
+constexpr int RG = 8;                    // columns a wave handles at once (independent loads in flight)
+
+// out0[c] = Vm(:, c)^T x0, out1[c] = Vm(:, c)^T x1 over rows [lo(c), hi(c)) for c in [0, kcols):
+// lo = (from_diag ? c : row_lo), hi = (to_diag ? c + 1 : row_hi).  Each wave takes RG columns at a time.
+__device__ __forceinline__ void wave_dots(const double *Vm, int N, int kcols, const double *x0, const double *x1,
+                                          bool from_diag, int row_lo, bool to_diag, int row_hi, double *out0, double *out1)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c0 = wave * RG; c0 < kcols; c0 += (AT / 64) * RG) {
+        double d0[RG], d1[RG];
+#pragma unroll
+        for (int q = 0; q < RG; ++q) { d0[q] = 0.0; d1[q] = 0.0; }
+        const int cl = min(c0 + RG, kcols) - 1;                        // last column of the group
+        const int rbeg = from_diag ? c0 : row_lo, rend = to_diag ? cl + 1 : row_hi;
+        for (int r = rbeg + lane; r < rend; r += 64) {
+            const double a0 = x0[r], a1 = x1 ? x1[r] : 0.0;
+            double vv[RG];
+#pragma unroll
+            for (int q = 0; q < RG; ++q) {
+                const int c = c0 + q;
+                const bool in = c < kcols && r >= (from_diag ? c : row_lo) && r < (to_diag ? c + 1 : row_hi);
+                vv[q] = in ? Vm[(size_t)c * N + r] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < RG; ++q) { d0[q] += vv[q] * a0; d1[q] += vv[q] * a1; }
+        }
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+            for (int off = 32; off >= 1; off >>= 1) { d0[q] += __shfl_xor(d0[q], off, 64); d1[q] += __shfl_xor(d1[q], off, 64); }
+            if (lane == 0 && c0 + q < kcols) { out0[c0 + q] = d0[q]; if (out1) out1[c0 + q] = d1[q]; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
@@ -98,12 +134,18 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     const int n = a.n, N = 2 * n, m = a.m;
     const double *muY = a.muY + inst * a.s_mu, *SYY = a.SYY + inst * a.s_S, *y = a.y + inst * a.s_y;
     int32_t *idx = a.idx + inst * a.s_idx;
-    double *V = a.ws + inst * a.s_ws, *T = V + (size_t)N * N, *z = T + (size_t)N * N;
+    extern __shared__ double vecs[];         // the 11 N doubles of work vectors when they fit (a.vec_lds)
+    double *V = a.ws + inst * a.s_ws, *T = V + (size_t)N * N, *z = a.vec_lds ? vecs : T + (size_t)N * N;
     double *ca = z + N, *cb = ca + 2 * N, *w = cb + 2 * N, *u = w + 2 * N, *tv = u + 2 * N;
     uint8_t *avail = a.avail + inst * a.s_av;
     const double halflog2pi = log(3.14159265358979323846264338327950288 * 2) / 2;
 
     int k = 0, nA = 0;                       // accepted reflectors / associated landmarks
+    int cursor = 0;                          // state of the offer-list walk (mode 0)
+    if (a.mode == 0) {
+        for (int i = tid; i < m; i += AT) avail[i] = 1;
+        __syncthreads();
+    }
     double zz = 0.0, logdet = 0.0, s = n * a.sU;
     for (int j = 0; j < n; ++j) {
         const int given = a.mode == 1 ? idx[j] : -2;
@@ -115,26 +157,21 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         }
         __syncthreads();
         if (k > 0) {
-            for (int c = wave; c < k; c += AT / 64) {               // w = V^T ca, one wave per reflector
-                const double *vc = V + (size_t)c * N;
-                double d0 = 0.0, d1 = 0.0;
-                for (int r = c + lane; r < N; r += 64) { const double vv = vc[r]; d0 += vv * ca[r]; d1 += vv * ca[N + r]; }
-                for (int off = 32; off >= 1; off >>= 1) { d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); }
-                if (lane == 0) { w[c] = d0; w[N + c] = d1; }
-            }
+            wave_dots(V, N, k, ca, ca + N, true, 0, false, N, w, w + N);      // w = V^T ca  (v_c is zero above row c)
             __syncthreads();
-            for (int c = tid; c < 2 * k; c += AT) {                 // u = T^T w
-                const int q = c / k, cc = c % k;
-                const double *tc = T + (size_t)cc * N;
-                double acc = 0.0;
-                for (int l = 0; l <= cc; ++l) acc += tc[l] * w[q * N + l];
-                u[q * N + cc] = acc;
-            }
+            wave_dots(T, N, k, w, w + N, false, 0, true, 0, u, u + N);       // u = T^T w   (T upper triangular)
             __syncthreads();
             for (int r = tid; r < 2 * N; r += AT) {                 // ca -= V u
                 const int q = r / N, rr = r % N;
                 double acc = 0.0;
-                for (int c = 0; c < k && c <= rr; ++c) acc += V[(size_t)c * N + rr] * u[q * N + c];
+                // uniform trip count (v_c is stored with its zeros above row c), 16 independent loads per step
+                for (int c0 = 0; c0 < k; c0 += 16) {
+                    double vv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) vv[e] = (c0 + e < k) ? V[(size_t)(c0 + e) * N + rr] : 0.0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc += vv[e] * ((c0 + e < k) ? u[q * N + c0 + e] : 0.0);
+                }
                 ca[r] -= acc;
             }
             __syncthreads();
@@ -159,17 +196,8 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
             apply_reflector(cb, ti0, 0, N, cb + N, red);
             const double i01 = cb[N];
             const double ib1 = make_reflector(cb + N, 1, N, red, &ti1);
-            // ---- features still on offer (literal std::set_difference walk over idx[0..j)) ----
-            for (int i = tid; i < m; i += AT) avail[i] = 1;
-            __syncthreads();
-            if (tid == 0) {
-                int cursor = 0;
-                for (int q = 0; q < j; ++q) {
-                    const int v = idx[q];
-                    if (v >= cursor && v < m) { avail[v] = 0; cursor = v + 1; }
-                }
-            }
-            __syncthreads();
+            // ---- features still on offer: avail[] holds the std::set_difference walk over idx[0..j), kept up
+            //      to date as associations are made (see the end of the loop body) ----
             // ---- candidates ----
             double my_ds = INFINITY, my_z0 = 0.0, my_z1 = 0.0;
             int my_i = 0x7fffffff;
@@ -218,7 +246,16 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
             best_z0 = (e0 - c0) / beta0;
             best_z1 = (e1 - c1 - r01 * best_z0) / beta1;
         }
-        if (a.mode == 0 && tid == 0) idx[j] = best_i;
+        if (a.mode == 0) {
+            // The reference rebuilds the offer list for every landmark by walking idx[0..j) with one cursor; the
+            // walk over a prefix never changes, so one step per landmark continues it: idx[j] is withheld from
+            // later landmarks only if it is not below the cursor.
+            if (best_i >= cursor && best_i < m) {
+                if (tid == 0) avail[best_i] = 0;
+                cursor = best_i + 1;
+            }
+            if (tid == 0) idx[j] = best_i;
+        }
         if (best_i < 0) { __syncthreads(); continue; }
         // ---- commit: V, T, z, running sums grow by two ----
         for (int q = 0; q < 2; ++q) {
@@ -228,18 +265,18 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
             double *vc = V + (size_t)kk * N;
             for (int r = tid; r < N; r += AT) vc[r] = r < kk ? 0.0 : (r == kk ? 1.0 : src[r]);
             __syncthreads();
-            for (int c = wave; c < kk; c += AT / 64) {              // tv = V(:, 0:kk)^T v
-                const double *vo = V + (size_t)c * N;
-                double d = 0.0;
-                for (int r = kk + lane; r < N; r += 64) d += vo[r] * vc[r];
-                for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-                if (lane == 0) tv[c] = d;
-            }
+            wave_dots(V, N, kk, vc, nullptr, false, kk, false, N, tv, nullptr);   // tv = V(:, 0:kk)^T v  (v is zero above row kk)
             __syncthreads();
             double *tc = T + (size_t)kk * N;
             for (int r = tid; r < kk; r += AT) {                    // T(0:kk, kk) = -tau T(0:kk,0:kk) tv
                 double acc = 0.0;
-                for (int l = r; l < kk; ++l) acc += T[(size_t)l * N + r] * tv[l];
+                for (int l0 = r & ~15; l0 < kk; l0 += 16) {         // T is upper triangular: columns l >= r of row r
+                    double tt[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { const int l = l0 + e; tt[e] = (l >= r && l < kk) ? T[(size_t)l * N + r] : 0.0; }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { const int l = l0 + e; acc += tt[e] * ((l >= r && l < kk) ? tv[l] : 0.0); }
+                }
                 tc[r] = -tau * acc;
             }
             if (tid == 0) tc[kk] = tau;
@@ -336,7 +373,14 @@ size_t assoc_ws_doubles(int n) { const size_t N = 2 * (size_t)n; return 2 * N * 
 // Queues the association kernel for `batch` instances; every pointer is device memory.
 vslam_status assoc_launch(vslam_ctx *ctx, AssocArgs a, int batch)
 {
-    hipLaunchKernelGGL(assoc_kernel, dim3(batch), dim3(AT), 0, ctx->stream, a);
+    // The work vectors (z, two column pairs, w, u, t: 11 N doubles) live in LDS when they fit: every phase
+    // boundary is then an LDS round trip instead of one through L2.
+    const size_t vec_bytes = (size_t)11 * 2 * a.n * sizeof(double);
+    a.vec_lds = vec_bytes <= 144 * 1024;
+    const size_t lds = a.vec_lds ? vec_bytes : 0;
+    if (lds > 48 * 1024)
+        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(assoc_kernel, dim3(batch), dim3(AT), lds, ctx->stream, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
