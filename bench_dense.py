@@ -1,6 +1,7 @@
 """Dense fp64 leg of bench.py (rank 0, one GPU): the square-root re-triangularisation QR of the
 2,000-landmark state (6012 x 6012, device resident) against the fp64 matrix-core peak, and the
-wall time of one complete measurement update (150 landmarks) on both trust-region routes."""
+wall time of one complete measurement update (150 landmarks) on both trust-region routes, and the
+per-frame steps either side of it (time update, data association, descriptor matching)."""
 import time
 
 import numpy as np
@@ -44,8 +45,55 @@ def run_dense_leg(ctx, dev, stream):
         out = api.measurement_update_iekf(hctx, cam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
         upd[name] = (time.perf_counter() - t0) * 1e3
         upd["iterations"] = out[3]
+    # the per-frame steps either side of the update: time update, data association, descriptor matching
+    pt, ot = np.diag([0.5, 0.5, 0.175]), np.diag([0.05, 0.05, 0.05])
+    frame = {}
+    x = sc.x.copy()
+    x[:6] = 0.2 * np.random.default_rng(1).standard_normal(6)
+    api.time_update(hctx, x, sc.S, pt, ot, 1 / 30)
+    t0 = time.perf_counter()
+    api.time_update(hctx, x, sc.S, pt, ot, 1 / 30)
+    frame["time_update_ms"] = (time.perf_counter() - t0) * 1e3
+    B = 512
+    mu_b = torch.tensor(x, device=dev).repeat(B, 1).contiguous()
+    S_b = torch.tensor(np.ascontiguousarray(sc.S.T), device=dev).repeat(B, 1, 1).contiguous()
+    mu_o, S_o = torch.empty_like(mu_b), torch.empty_like(S_b)
+    api.time_update_batch_dev(ctx, mu_b, S_b, sc.n, pt, ot, 1 / 30, mu_o, S_o)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    api.time_update_batch_dev(ctx, mu_b, S_b, sc.n, pt, ot, 1 / 30, mu_o, S_o)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    frame["time_update_512_filters_ms"] = e0.elapsed_time(e1)
+    del mu_b, S_b, mu_o, S_o
+    rng = np.random.default_rng(80)
+    feats = np.concatenate([sc.pixel_true + 2.0 * rng.standard_normal((sc.L, 2)),
+                            np.stack([rng.uniform(0, 1920, sc.L), rng.uniform(0, 1080, sc.L)], axis=1)])
+    yf = feats[rng.permutation(feats.shape[0])].T.copy()
+    api.snn(hctx, cam, sc.x, sc.S, yf)
+    t0 = time.perf_counter()
+    api.snn(hctx, cam, sc.x, sc.S, yf)
+    frame["snn_ms"] = (time.perf_counter() - t0) * 1e3
+    Bm, nq, nt = 64, 150, 10000                         # 64 frames: 150 landmark descriptors against 10,000 ORB features
+    gen.manual_seed(6)
+    tq = torch.randint(0, 256, (Bm, nq, 32), dtype=torch.uint8, device=dev, generator=gen)
+    tt = torch.randint(0, 256, (Bm, nt, 32), dtype=torch.uint8, device=dev, generator=gen)
+    mi = torch.zeros((Bm, nq), dtype=torch.int32, device=dev)
+    api.match_hamming_batch_dev(ctx, tq, tt, mi)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(10):
+        api.match_hamming_batch_dev(ctx, tq, tt, mi)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    mms = e0.elapsed_time(e1) / 10
+    frame["match_hamming_64_frames_ms"] = mms
+    frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
     return {
+        "frame_steps_150_landmarks": frame,
         "qr": {"workload": "in-place Householder QR (R only), %d x %d fp64, device resident" % (n, n), "ms": ms,
                "roofline": {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "algorithmic_flops": flops}},
