@@ -28,6 +28,7 @@
 // keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
 // unpacks the leading keys into Feature records.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace vslam {
 
@@ -317,6 +318,138 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
     }
 }
 
+// ---- sliding-window detector (7x7 window, keypoints only) -------------------------------------
+// One wavefront owns a 64-column strip (54 output columns + a 5-pixel halo either side) of a band of
+// rows and walks down it one image row per step; lane l is column xs + l.  Nothing is recomputed
+// vertically: the three newest pixel rows, a seven-row ring of horizontal window sums, the running
+// vertical sums and the last three response rows live in registers.  Horizontal neighbours come from
+// cross-lane reads (ds_bpermute), so there is no LDS tile and no barrier.  Step t takes pixel row t:
+//   gradient row t-1 -> products -> horizontal 7-sums -> ring -> vertical sums = window of row t-4
+//   -> responses of row t-4 -> non-maximum suppression of row t-5.
+// Same integer and float operations per pixel as corner_tile_kernel, so the keypoints are identical.
+constexpr int SW_HALO = 5, SW_OUT = 64 - 2 * SW_HALO;
+
+__device__ __forceinline__ int lane_read_i(int v, int addr) { return __builtin_amdgcn_ds_bpermute(addr, v); }
+__device__ __forceinline__ float lane_read_f(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+
+template <int DET>
+__global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstrips, int nseg, int seg_h)
+{
+    __shared__ uint64_t stage[2][128];
+    const int lane = threadIdx.x;
+    int bid = blockIdx.x;
+    const int strip = bid % nstrips; bid /= nstrips;
+    const int seg = bid % nseg, frame = bid / nseg;
+    const int w = a.w, h = a.h;
+    const int ya = seg * seg_h, yb = min(h, ya + seg_h);
+    if (ya >= yb) return;
+    const int gx = strip * SW_OUT - SW_HALO + lane;
+    const uint8_t *colp = a.gray + (size_t)frame * a.stride_frame + min(max(gx, 0), w - 1);
+    // byte addresses of the lanes at distance -3..+3 for ds_bpermute (wrapping; wrapped values only reach halo lanes)
+    const int am1 = ((lane - 1) & 63) << 2, ap1 = ((lane + 1) & 63) << 2, ap2 = ((lane + 2) & 63) << 2;
+    const int am3 = ((lane - 3) & 63) << 2, ap3 = ((lane + 3) & 63) << 2;
+    constexpr int R = 4;                                      // response needs the image +-R (7x7 window of 3x3 gradients)
+    const bool col_valid = gx >= R && gx < w - R;
+    const bool col_out = lane >= SW_HALO && lane < 64 - SW_HALO && gx >= a.border && gx < w - a.border;
+    int cnt[2] = {0, 0};                                      // staged keys per detector (wave-uniform)
+    uint64_t *cand_h = a.cand + ((size_t)frame * 2 + 0) * CAND_CAP, *cand_s = a.cand + ((size_t)frame * 2 + 1) * CAND_CAP;
+
+    int r0 = 0, r1 = 0, r2 = 0;                               // pixel rows t-2, t-1, t
+    int ring_a[7], ring_b[7], ring_c[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { ring_a[u] = 0; ring_b[u] = 0; ring_c[u] = 0; }
+    int va = 0, vb = 0, vc = 0;
+    // per detector: centre row value / left / right, 3-maximum of the row above the centre and of the centre row
+    float cv[2] = {0.f, 0.f}, cl[2] = {0.f, 0.f}, cr[2] = {0.f, 0.f}, m_up[2] = {0.f, 0.f}, m_c[2] = {0.f, 0.f};
+
+    const int tstart = ya - 6, tend = yb + 5;                 // steps [tstart, tend)
+    int nxt[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) nxt[u] = colp[(size_t)min(max(tstart + u, 0), h - 1) * a.stride];
+    for (int t0 = tstart; t0 < tend; t0 += 7) {
+        int cur[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) nxt[u] = colp[(size_t)min(max(t0 + 7 + u, 0), h - 1) * a.stride];   // next block's rows, in flight during this one
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int t = t0 + u;
+            if (t >= tend) break;
+            r0 = r1; r1 = r2; r2 = cur[u];
+            // Sobel of row t-1, separable: smooth = r0 + 2 r1 + r2, diff = r2 - r0
+            const int sm = r0 + 2 * r1 + r2, df = r2 - r0;
+            const int ix = lane_read_i(sm, ap1) - lane_read_i(sm, am1);
+            const int iy = lane_read_i(df, am1) + 2 * df + lane_read_i(df, ap1);
+            const int pa = __mul24(ix, ix), pb = __mul24(iy, iy), pc = __mul24(ix, iy);
+            // horizontal 7-sums: pairs, quads, then x-3..x | x+1,x+2 | x+3
+            const int a2 = pa + lane_read_i(pa, ap1), b2 = pb + lane_read_i(pb, ap1), c2 = pc + lane_read_i(pc, ap1);
+            const int a4 = a2 + lane_read_i(a2, ap2), b4 = b2 + lane_read_i(b2, ap2), c4 = c2 + lane_read_i(c2, ap2);
+            const int ha = lane_read_i(a4, am3) + lane_read_i(a2, ap1) + lane_read_i(pa, ap3);
+            const int hb = lane_read_i(b4, am3) + lane_read_i(b2, ap1) + lane_read_i(pb, ap3);
+            const int hc = lane_read_i(c4, am3) + lane_read_i(c2, ap1) + lane_read_i(pc, ap3);
+            va += ha - ring_a[u]; ring_a[u] = ha;
+            vb += hb - ring_b[u]; ring_b[u] = hb;
+            vc += hc - ring_c[u]; ring_c[u] = hc;
+            // responses of row yr = t - 4
+            const int yr = t - 4;
+            const bool valid = col_valid && yr >= R && yr < h - R;
+            const float fa = (float)va, fb = (float)vb, fc = (float)vc;
+            const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
+            float resp[2] = {0.f, 0.f};
+            if (DET & 1) {
+                const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
+                const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
+                resp[0] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
+            }
+            if (DET & 2) {
+                const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
+                const float root = sqrtf(__fadd_rn(__fmul_rn(d, d), t2));     // correctly rounded (see vslam_debug_sqrtf_mismatches)
+                resp[1] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+            }
+            // non-maximum suppression of row yc = t - 5 with the rows above (m_up) and below (this one)
+            const int yc = t - 5;
+            const bool row_out = yc >= ya && yc < yb && yc >= a.border && yc < h - a.border;
+#pragma unroll
+            for (int det = 0; det < 2; ++det) {
+                if (!(DET & (1 << det))) continue;
+                const float r = resp[det];
+                const float l = lane_read_f(r, am1), rr = lane_read_f(r, ap1);
+                const float m_dn = fmaxf(fmaxf(l, r), rr);
+                const float c = cv[det];
+                const float thr = det == 0 ? a.thr_h : a.thr_s;
+                const bool hit = row_out && col_out && c > thr && c > m_up[det] && c > cl[det] && c >= cr[det] && c >= m_dn;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    const int pos = cnt[det] + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (hit) stage[det][pos] = make_key(c, gx, yc);
+                    cnt[det] += __popcll(mask);
+                    if (cnt[det] >= 64) {                    // flush one full wave of keys
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(a.cand_count + ((size_t)frame * 2 + det), 64);
+                        base = __shfl(base, 0, 64);
+                        uint64_t *dst = det == 0 ? cand_h : cand_s;
+                        const uint64_t key = stage[det][lane], rest = stage[det][64 + lane];
+                        if (base + lane < CAND_CAP) dst[base + lane] = key;
+                        stage[det][lane] = rest;
+                        cnt[det] -= 64;
+                    }
+                }
+                m_up[det] = m_c[det]; m_c[det] = m_dn; cv[det] = r; cl[det] = l; cr[det] = rr;
+            }
+        }
+    }
+#pragma unroll
+    for (int det = 0; det < 2; ++det) {
+        if (!(DET & (1 << det)) || cnt[det] == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.cand_count + ((size_t)frame * 2 + det), cnt[det]);
+        base = __shfl(base, 0, 64);
+        uint64_t *dst = det == 0 ? cand_h : cand_s;
+        if (lane < cnt[det] && base + lane < CAND_CAP) dst[base + lane] = stage[det][lane];
+    }
+}
+
 // Bitonic sort (descending) of one chunk of candidate keys in LDS.
 // grid = (CAND_CHUNKS, frames, 2 detectors); chunks beyond the candidate count exit.
 __global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
@@ -452,7 +585,19 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     dim3 grid((unsigned)((size_t)a.tiles_x * ((a.h + TH - 1) / TH) * frames));
     size_t lds = tile_lds_bytes(a.bs);
     const int det_mask = detector == 2 ? 3 : (1 << detector);
-    if (a.bs == 7) {
+    if (a.bs == 7 && !getenv("VSLAM_CORNER_TILE")) {
+        const int nstrips = (a.w + SW_OUT - 1) / SW_OUT;
+        // bands of rows: enough wavefronts to fill the chip, at least 64 rows each (11 extra steps per band)
+        int nseg = (16384 + nstrips * frames - 1) / (nstrips * frames);
+        const int max_seg = (a.h + 63) / 64;
+        if (nseg > max_seg) nseg = max_seg;
+        if (nseg < 1) nseg = 1;
+        const int seg_h = (a.h + nseg - 1) / nseg;
+        dim3 sgrid((unsigned)((size_t)nstrips * nseg * frames));
+        if (det_mask == 1) hipLaunchKernelGGL((corner_strip_kernel<1>), sgrid, dim3(64), 0, s, a, nstrips, nseg, seg_h);
+        else if (det_mask == 2) hipLaunchKernelGGL((corner_strip_kernel<2>), sgrid, dim3(64), 0, s, a, nstrips, nseg, seg_h);
+        else hipLaunchKernelGGL((corner_strip_kernel<3>), sgrid, dim3(64), 0, s, a, nstrips, nseg, seg_h);
+    } else if (a.bs == 7) {
         if (det_mask == 1) hipLaunchKernelGGL((corner_tile_kernel<1, false, 7>), grid, dim3(256), lds, s, a);
         else if (det_mask == 2) hipLaunchKernelGGL((corner_tile_kernel<2, false, 7>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((corner_tile_kernel<3, false, 7>), grid, dim3(256), lds, s, a);
