@@ -319,15 +319,17 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 }
 
 // ---- sliding-window detector (7x7 window, keypoints only) -------------------------------------
-// One wavefront owns a 64-column strip (54 output columns + a 5-pixel halo either side) of a band of
-// rows and walks down it one image row per step; lane l is column xs + l.  Nothing is recomputed
-// vertically: the three newest pixel rows, a seven-row ring of horizontal window sums, the running
-// vertical sums and the last three response rows live in registers.  Horizontal neighbours come from
-// cross-lane reads (ds_bpermute), so there is no LDS tile and no barrier.  Step t takes pixel row t:
+// One wavefront owns a 128-column strip (116 output columns + a 6-pixel halo either side) of a band
+// of rows and walks down it one image row per step; lane l holds the column pair xs + 2l (E) and
+// xs + 2l + 1 (O).  Nothing is recomputed vertically: the three newest pixel rows, a seven-row ring of
+// horizontal window sums, the running vertical sums and the last response rows live in registers.
+// Horizontal neighbours are the lane's other column or come from cross-lane reads (ds_bpermute) of
+// neighbouring lanes -- a 7-wide window of a column pair is  odd(l-2) + pair(l-1) + pair(l) +
+// pair(l+1) [+ even(l+2)] -- so there is no LDS tile and no barrier.  Step t takes pixel row t:
 //   gradient row t-1 -> products -> horizontal 7-sums -> ring -> vertical sums = window of row t-4
 //   -> responses of row t-4 -> non-maximum suppression of row t-5.
 // Same integer and float operations per pixel as corner_tile_kernel, so the keypoints are identical.
-constexpr int SW_HALO = 5, SW_OUT = 64 - 2 * SW_HALO;
+constexpr int SW_HALO = 6, SW_OUT = 128 - 2 * SW_HALO;
 
 __device__ __forceinline__ int lane_read_i(int v, int addr) { return __builtin_amdgcn_ds_bpermute(addr, v); }
 __device__ __forceinline__ float lane_read_f(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
@@ -343,69 +345,115 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
     const int w = a.w, h = a.h;
     const int ya = seg * seg_h, yb = min(h, ya + seg_h);
     if (ya >= yb) return;
-    const int gx = strip * SW_OUT - SW_HALO + lane;
-    const uint8_t *colp = a.gray + (size_t)frame * a.stride_frame + min(max(gx, 0), w - 1);
-    // byte addresses of the lanes at distance -3..+3 for ds_bpermute (wrapping; wrapped values only reach halo lanes)
-    const int am1 = ((lane - 1) & 63) << 2, ap1 = ((lane + 1) & 63) << 2, ap2 = ((lane + 2) & 63) << 2;
-    const int am3 = ((lane - 3) & 63) << 2, ap3 = ((lane + 3) & 63) << 2;
+    const int gx0 = strip * SW_OUT - SW_HALO + 2 * lane;      // column E; O is gx0 + 1
+    const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
+    const uint8_t *colp[2] = {gray + min(max(gx0, 0), w - 1), gray + min(max(gx0 + 1, 0), w - 1)};
+    // byte addresses of the neighbouring lanes for ds_bpermute (wrapping; wrapped values only reach halo columns)
+    const int am1 = ((lane - 1) & 63) << 2, ap1 = ((lane + 1) & 63) << 2, am2 = ((lane - 2) & 63) << 2, ap2 = ((lane + 2) & 63) << 2;
     constexpr int R = 4;                                      // response needs the image +-R (7x7 window of 3x3 gradients)
-    const bool col_valid = gx >= R && gx < w - R;
-    const bool col_out = lane >= SW_HALO && lane < 64 - SW_HALO && gx >= a.border && gx < w - a.border;
+    bool col_valid[2], col_out[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int gx = gx0 + e, off = 2 * lane + e;
+        col_valid[e] = gx >= R && gx < w - R;
+        col_out[e] = off >= SW_HALO && off < 128 - SW_HALO && gx >= a.border && gx < w - a.border;
+    }
     int cnt[2] = {0, 0};                                      // staged keys per detector (wave-uniform)
-    uint64_t *cand_h = a.cand + ((size_t)frame * 2 + 0) * CAND_CAP, *cand_s = a.cand + ((size_t)frame * 2 + 1) * CAND_CAP;
 
-    int r0 = 0, r1 = 0, r2 = 0;                               // pixel rows t-2, t-1, t
-    int ring_a[7], ring_b[7], ring_c[7];
+    int r0[2] = {0, 0}, r1[2] = {0, 0}, r2[2] = {0, 0};       // pixel rows t-2, t-1, t
+    int ring[7][2][3];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) { ring_a[u] = 0; ring_b[u] = 0; ring_c[u] = 0; }
-    int va = 0, vb = 0, vc = 0;
-    // per detector: centre row value / left / right, 3-maximum of the row above the centre and of the centre row
-    float cv[2] = {0.f, 0.f}, cl[2] = {0.f, 0.f}, cr[2] = {0.f, 0.f}, m_up[2] = {0.f, 0.f}, m_c[2] = {0.f, 0.f};
+    for (int u = 0; u < 7; ++u)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { ring[u][e][0] = 0; ring[u][e][1] = 0; ring[u][e][2] = 0; }
+    int vs[2][3] = {{0, 0, 0}, {0, 0, 0}};                    // vertical window sums of a, b, c
+    // per detector and column: centre-row value, 3-maximum of the row above the centre and of the centre row;
+    // cl: left neighbour of E (O of lane l-1), cr: right neighbour of O (E of lane l+1), both of the centre row
+    float cv[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, m_up[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, m_c[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float cl[2] = {0.f, 0.f}, cr[2] = {0.f, 0.f};
 
-    const int tstart = ya - 6, tend = yb + 5;                 // steps [tstart, tend)
-    int nxt[7];
+    // appends the keys of the lanes with `hit`; a full wave of staged keys goes out with one reservation
+    auto emit = [&](int det, bool hit, float score, int x, int y) {
+        const unsigned long long mask = __ballot(hit);
+        if (!mask) return;
+        const int pos = cnt[det] + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit) stage[det][pos] = make_key(score, x, y);
+        cnt[det] += __popcll(mask);
+        if (cnt[det] >= 64) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.cand_count + ((size_t)frame * 2 + det), 64);
+            base = __shfl(base, 0, 64);
+            uint64_t *dst = a.cand + ((size_t)frame * 2 + det) * CAND_CAP;
+            const uint64_t key = stage[det][lane], rest = stage[det][64 + lane];
+            if (base + lane < CAND_CAP) dst[base + lane] = key;
+            stage[det][lane] = rest;
+            cnt[det] -= 64;
+        }
+    };
+
+    const int tstart = ya - 6, tend = yb + 5;                 // steps [tstart, tend), run in blocks of 7 (the ring size)
+    int nxt[7][2];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) nxt[u] = colp[(size_t)min(max(tstart + u, 0), h - 1) * a.stride];
+    for (int u = 0; u < 7; ++u) {
+        const size_t ro = (size_t)min(max(tstart + u, 0), h - 1) * a.stride;
+        nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
+    }
     for (int t0 = tstart; t0 < tend; t0 += 7) {
-        int cur[7];
+        int cur[7][2];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < 7; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
 #pragma unroll
-        for (int u = 0; u < 7; ++u) nxt[u] = colp[(size_t)min(max(t0 + 7 + u, 0), h - 1) * a.stride];   // next block's rows, in flight during this one
+        for (int u = 0; u < 7; ++u) {                          // next block's rows, in flight during this one
+            const size_t ro = (size_t)min(max(t0 + 7 + u, 0), h - 1) * a.stride;
+            nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
+        }
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
+        for (int u = 0; u < 7; ++u) {                          // steps past tend only touch rows no band emits
             const int t = t0 + u;
-            if (t >= tend) break;
-            r0 = r1; r1 = r2; r2 = cur[u];
-            // Sobel of row t-1, separable: smooth = r0 + 2 r1 + r2, diff = r2 - r0
-            const int sm = r0 + 2 * r1 + r2, df = r2 - r0;
-            const int ix = lane_read_i(sm, ap1) - lane_read_i(sm, am1);
-            const int iy = lane_read_i(df, am1) + 2 * df + lane_read_i(df, ap1);
-            const int pa = __mul24(ix, ix), pb = __mul24(iy, iy), pc = __mul24(ix, iy);
-            // horizontal 7-sums: pairs, quads, then x-3..x | x+1,x+2 | x+3
-            const int a2 = pa + lane_read_i(pa, ap1), b2 = pb + lane_read_i(pb, ap1), c2 = pc + lane_read_i(pc, ap1);
-            const int a4 = a2 + lane_read_i(a2, ap2), b4 = b2 + lane_read_i(b2, ap2), c4 = c2 + lane_read_i(c2, ap2);
-            const int ha = lane_read_i(a4, am3) + lane_read_i(a2, ap1) + lane_read_i(pa, ap3);
-            const int hb = lane_read_i(b4, am3) + lane_read_i(b2, ap1) + lane_read_i(pb, ap3);
-            const int hc = lane_read_i(c4, am3) + lane_read_i(c2, ap1) + lane_read_i(pc, ap3);
-            va += ha - ring_a[u]; ring_a[u] = ha;
-            vb += hb - ring_b[u]; ring_b[u] = hb;
-            vc += hc - ring_c[u]; ring_c[u] = hc;
-            // responses of row yr = t - 4
-            const int yr = t - 4;
-            const bool valid = col_valid && yr >= R && yr < h - R;
-            const float fa = (float)va, fb = (float)vb, fc = (float)vc;
-            const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
-            float resp[2] = {0.f, 0.f};
-            if (DET & 1) {
-                const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
-                const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
-                resp[0] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
+            int sm[2], df[2], pk[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                r0[e] = r1[e]; r1[e] = r2[e]; r2[e] = cur[u][e];
+                sm[e] = r0[e] + 2 * r1[e] + r2[e];             // Sobel of row t-1, separable: smooth and difference
+                df[e] = r2[e] - r0[e];
+                pk[e] = (sm[e] << 16) | (df[e] & 0xffff);
             }
-            if (DET & 2) {
-                const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
-                const float root = sqrtf(__fadd_rn(__fmul_rn(d, d), t2));     // correctly rounded (see vslam_debug_sqrtf_mismatches)
-                resp[1] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+            const int pk_l = lane_read_i(pk[1], am1), pk_r = lane_read_i(pk[0], ap1);   // O of lane l-1, E of lane l+1
+            const int sm_l = (int)((unsigned)pk_l >> 16), df_l = (pk_l << 16) >> 16;
+            const int sm_r = (int)((unsigned)pk_r >> 16), df_r = (pk_r << 16) >> 16;
+            const int ix[2] = {sm[1] - sm_l, sm_r - sm[0]};
+            const int iy[2] = {df_l + 2 * df[0] + df[1], df[0] + 2 * df[1] + df_r};
+            int hs[2][3];                                      // horizontal 7-sums of the products
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int pe = ch == 0 ? __mul24(ix[0], ix[0]) : (ch == 1 ? __mul24(iy[0], iy[0]) : __mul24(ix[0], iy[0]));
+                const int po = ch == 0 ? __mul24(ix[1], ix[1]) : (ch == 1 ? __mul24(iy[1], iy[1]) : __mul24(ix[1], iy[1]));
+                const int pr = pe + po;
+                const int mid = lane_read_i(pr, am1) + pr + lane_read_i(pr, ap1);
+                hs[0][ch] = lane_read_i(po, am2) + mid;
+                hs[1][ch] = mid + lane_read_i(pe, ap2);
+            }
+            const int yr = t - 4;                              // responses of row yr
+            const bool row_valid = yr >= R && yr < h - R;
+            float resp[2][2];                                  // [detector][column]
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { vs[e][ch] += hs[e][ch] - ring[u][e][ch]; ring[u][e][ch] = hs[e][ch]; }
+                const bool valid = col_valid[e] && row_valid;
+                const float fa = (float)vs[e][0], fb = (float)vs[e][1], fc = (float)vs[e][2];
+                const float t2 = __fmul_rn(fc, fc), t4 = __fadd_rn(fa, fb);
+                resp[0][e] = 0.f; resp[1][e] = 0.f;
+                if (DET & 1) {
+                    const float t3 = __fsub_rn(__fmul_rn(fa, fb), t2);
+                    const float t6 = __fmul_rn(a.k, __fmul_rn(t4, t4));
+                    resp[0][e] = valid ? __fmul_rn(__fsub_rn(t3, t6), a.s4) : 0.0f;
+                }
+                if (DET & 2) {
+                    const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
+                    const float root = sqrtf(__fadd_rn(__fmul_rn(d, d), t2));     // correctly rounded (see vslam_debug_sqrtf_mismatches)
+                    resp[1][e] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
+                }
             }
             // non-maximum suppression of row yc = t - 5 with the rows above (m_up) and below (this one)
             const int yc = t - 5;
@@ -413,29 +461,18 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
 #pragma unroll
             for (int det = 0; det < 2; ++det) {
                 if (!(DET & (1 << det))) continue;
-                const float r = resp[det];
-                const float l = lane_read_f(r, am1), rr = lane_read_f(r, ap1);
-                const float m_dn = fmaxf(fmaxf(l, r), rr);
-                const float c = cv[det];
+                const float re = resp[det][0], ro = resp[det][1];
+                const float l = lane_read_f(ro, am1), rr = lane_read_f(re, ap1);       // left of E, right of O
+                const float m_dn[2] = {fmaxf(fmaxf(l, re), ro), fmaxf(fmaxf(re, ro), rr)};
                 const float thr = det == 0 ? a.thr_h : a.thr_s;
-                const bool hit = row_out && col_out && c > thr && c > m_up[det] && c > cl[det] && c >= cr[det] && c >= m_dn;
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    const int pos = cnt[det] + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (hit) stage[det][pos] = make_key(c, gx, yc);
-                    cnt[det] += __popcll(mask);
-                    if (cnt[det] >= 64) {                    // flush one full wave of keys
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(a.cand_count + ((size_t)frame * 2 + det), 64);
-                        base = __shfl(base, 0, 64);
-                        uint64_t *dst = det == 0 ? cand_h : cand_s;
-                        const uint64_t key = stage[det][lane], rest = stage[det][64 + lane];
-                        if (base + lane < CAND_CAP) dst[base + lane] = key;
-                        stage[det][lane] = rest;
-                        cnt[det] -= 64;
-                    }
-                }
-                m_up[det] = m_c[det]; m_c[det] = m_dn; cv[det] = r; cl[det] = l; cr[det] = rr;
+                const float ce = cv[det][0], co = cv[det][1];
+                const bool hit_e = row_out && col_out[0] && ce > thr && ce > m_up[det][0] && ce > cl[det] && ce >= co && ce >= m_dn[0];
+                const bool hit_o = row_out && col_out[1] && co > thr && co > m_up[det][1] && co > ce && co >= cr[det] && co >= m_dn[1];
+                emit(det, hit_e, ce, gx0, yc);
+                emit(det, hit_o, co, gx0 + 1, yc);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { m_up[det][e] = m_c[det][e]; m_c[det][e] = m_dn[e]; }
+                cv[det][0] = re; cv[det][1] = ro; cl[det] = l; cr[det] = rr;
             }
         }
     }
@@ -445,7 +482,7 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
         int base = 0;
         if (lane == 0) base = atomicAdd(a.cand_count + ((size_t)frame * 2 + det), cnt[det]);
         base = __shfl(base, 0, 64);
-        uint64_t *dst = det == 0 ? cand_h : cand_s;
+        uint64_t *dst = a.cand + ((size_t)frame * 2 + det) * CAND_CAP;
         if (lane < cnt[det] && base + lane < CAND_CAP) dst[base + lane] = stage[det][lane];
     }
 }
@@ -588,7 +625,7 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     if (a.bs == 7 && !getenv("VSLAM_CORNER_TILE")) {
         const int nstrips = (a.w + SW_OUT - 1) / SW_OUT;
         // bands of rows: enough wavefronts to fill the chip, at least 64 rows each (11 extra steps per band)
-        int nseg = (16384 + nstrips * frames - 1) / (nstrips * frames);
+        int nseg = (8192 + nstrips * frames - 1) / (nstrips * frames);
         const int max_seg = (a.h + 63) / 64;
         if (nseg > max_seg) nseg = max_seg;
         if (nseg < 1) nseg = 1;
