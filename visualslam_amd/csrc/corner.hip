@@ -358,6 +358,10 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
         col_valid[e] = gx >= R && gx < w - R;
         col_out[e] = off >= SW_HALO && off < 128 - SW_HALO && gx >= a.border && gx < w - a.border;
     }
+    // per column threshold: +inf where the column is halo or outside the border, so it never yields a keypoint
+    float thr_col[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { thr_col[0][e] = col_out[e] ? a.thr_h : INFINITY; thr_col[1][e] = col_out[e] ? a.thr_s : INFINITY; }
     int cnt[2] = {0, 0};                                      // staged keys per detector (wave-uniform)
 
     int r0[2] = {0, 0}, r1[2] = {0, 0}, r2[2] = {0, 0};       // pixel rows t-2, t-1, t
@@ -464,12 +468,14 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
                 const float re = resp[det][0], ro = resp[det][1];
                 const float l = lane_read_f(ro, am1), rr = lane_read_f(re, ap1);       // left of E, right of O
                 const float m_dn[2] = {fmaxf(fmaxf(l, re), ro), fmaxf(fmaxf(re, ro), rr)};
-                const float thr = det == 0 ? a.thr_h : a.thr_s;
                 const float ce = cv[det][0], co = cv[det][1];
-                const bool hit_e = row_out && col_out[0] && ce > thr && ce > m_up[det][0] && ce > cl[det] && ce >= co && ce >= m_dn[0];
-                const bool hit_o = row_out && col_out[1] && co > thr && co > m_up[det][1] && co > ce && co >= cr[det] && co >= m_dn[1];
-                emit(det, hit_e, ce, gx0, yc);
-                emit(det, hit_o, co, gx0 + 1, yc);
+                // strictly above the threshold, the row above and the left neighbour; at least the right neighbour and the row below
+                const bool hit_e = ce > fmaxf(fmaxf(thr_col[det][0], m_up[det][0]), cl[det]) && ce >= fmaxf(co, m_dn[0]);
+                const bool hit_o = co > fmaxf(fmaxf(thr_col[det][1], m_up[det][1]), ce) && co >= fmaxf(cr[det], m_dn[1]);
+                if (row_out && __ballot(hit_e || hit_o)) {
+                    emit(det, hit_e, ce, gx0, yc);
+                    emit(det, hit_o, co, gx0 + 1, yc);
+                }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { m_up[det][e] = m_c[det][e]; m_c[det][e] = m_dn[e]; }
                 cv[det][0] = re; cv[det][1] = ro; cl[det] = l; cr[det] = rr;
