@@ -403,21 +403,18 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
         nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
     }
     for (int t0 = tstart; t0 < tend; t0 += 7) {
-        int cur[7][2];
-#pragma unroll
-        for (int u = 0; u < 7; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {                          // next block's rows, in flight during this one
-            const size_t ro = (size_t)min(max(t0 + 7 + u, 0), h - 1) * a.stride;
-            nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
-        }
 #pragma unroll
         for (int u = 0; u < 7; ++u) {                          // steps past tend only touch rows no band emits
             const int t = t0 + u;
+            const int pix[2] = {nxt[u][0], nxt[u][1]};
+            {                                                  // row t + 7 takes this slot: seven rows stay in flight
+                const size_t ro = (size_t)min(max(t + 7, 0), h - 1) * a.stride;
+                nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
+            }
             int sm[2], df[2], pk[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                r0[e] = r1[e]; r1[e] = r2[e]; r2[e] = cur[u][e];
+                r0[e] = r1[e]; r1[e] = r2[e]; r2[e] = pix[e];
                 sm[e] = r0[e] + 2 * r1[e] + r2[e];             // Sobel of row t-1, separable: smooth and difference
                 df[e] = r2[e] - r0[e];
                 pk[e] = (sm[e] << 16) | (df[e] & 0xffff);
