@@ -89,6 +89,22 @@ def test_many_candidates_merge_path(ctx):
         assert np.array_equal(got["score"].view(np.uint32), want["score"].view(np.uint32))
 
 
+def test_strip_and_tile_kernels_agree_on_other_window_sizes(ctx):
+    """block_size 7 takes the sliding-window kernel, every other size the tiled kernel; both follow the
+    same contract, so each must equal the oracle on the same frame."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    gray = syn.frame(11, w=701, h=403, n_rect=80, n_disc=40)
+    for bs, border in ((5, 8), (7, 5), (7, 31), (9, 9)):
+        kw = dict(harris_thresh=1e-5, shi_thresh=3e-4, block_size=bs, border=border)
+        gp, op = api.corner_params(**kw), orc.corner_params(**kw)
+        for det in (0, 1):
+            got, want = api.corner_detect(ctx, gray, gp, det), orc.corner_detect(gray, op, det)
+            assert len(got) == len(want) and len(want) > 50
+            assert np.array_equal(got["x"], want["x"]) and np.array_equal(got["y"], want["y"])
+            assert np.array_equal(got["score"].view(np.uint32), want["score"].view(np.uint32))
+
+
 def test_no_keypoints_and_errors(ctx):
     from visualslam_amd import api
     flat = np.full((120, 160), 77, np.uint8)

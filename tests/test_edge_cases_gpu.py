@@ -7,10 +7,12 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("w,h", [(65, 33), (127, 64), (333, 217), (1921, 17), (16, 16), (12, 40)])
+@pytest.mark.parametrize("w,h", [(65, 33), (127, 64), (333, 217), (1921, 17), (16, 16), (12, 40),
+                                 (116, 70), (117, 129), (232, 65), (233, 200), (243, 131), (349, 64)])
 def test_corner_ragged_image_sizes(ctx, w, h):
-    """Widths that are not multiples of 4 or of the tile, images of a single tile row, and images smaller
-    than the borders (no valid pixel): maps bit-identical to the oracle, keypoints identical."""
+    """Widths that are not multiples of 4, of the tile or of the 116-column strips of the keypoint kernel,
+    heights around its row bands, images of a single tile row, and images smaller than the borders (no
+    valid pixel): maps bit-identical to the oracle, keypoints identical."""
     from oracle import pyoracle as orc
     from visualslam_amd import api
     rng = np.random.default_rng(w * 1000 + h)
