@@ -1,0 +1,91 @@
+"""One frame of the reference's point-landmark loop (src/SLAM.cpp:334-503) through the C ABI, step by step
+against the CPU oracle: time update -> descriptor matching -> data association -> landmark removal ->
+measurement update.  Each side feeds its own outputs forward, so the test also covers how the pieces
+compose (shapes, layouts, sign conventions of the factor handed from one step to the next).
+Tolerances are fp64 1e-9 per step, 1e-7 after the Newton iterations; integer outputs must be equal."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+PT = np.diag([0.5, 0.5, 0.175])        # scenario 2 process noise, src/SLAM.cpp:99-106
+OT = np.diag([0.05, 0.05, 0.05])
+
+
+def _signed(S):
+    d = np.sign(np.diag(S)).copy()
+    d[d == 0] = 1.0
+    return S * d[:, None]
+
+
+@pytest.mark.parametrize("solver", ["eig", "cholesky"])
+def test_one_frame_against_the_oracle(ctx, gcam, ocam, solver):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    L = 24
+    sc = syn.Scene(L, 77)
+    rng = np.random.default_rng(77)
+    x = sc.x.copy()
+    x[:6] = 0.05 * rng.standard_normal(6)                       # slow camera motion
+    dt = 1.0 / 30.0
+
+    # ---- time update (src/SLAM.cpp:337) ----
+    mu_g, S_g = api.time_update(ctx, x, sc.S, PT, OT, dt)
+    mu_o, S_o = orc.time_update(x, sc.S, PT, OT, dt)
+    assert rel_err(mu_g, mu_o) < 1e-9 and rel_err(S_g, S_o) < 1e-9
+
+    # ---- descriptor matching (src/SLAM.cpp:352-362): landmark descriptors against this frame's features ----
+    m = 60
+    feat_desc = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    seen = rng.permutation(m)[:L]                                # feature seen[j] is landmark j re-observed
+    lm_desc = feat_desc[seen].copy()
+    flip = rng.integers(0, 256, (L, 3))
+    for j in range(L):
+        for f in flip[j]:
+            lm_desc[j, f // 8] ^= np.uint8(1 << (f % 8))
+    tr_g, d_g = api.match_hamming(ctx, lm_desc, feat_desc)
+    tr_o, d_o = orc.match_hamming(lm_desc, feat_desc)
+    assert np.array_equal(tr_g, tr_o) and np.array_equal(d_g, d_o) and np.array_equal(tr_g, seen)
+
+    # potential measurements: the matched features' pixels (predicted pixel + noise; two landmarks get a far-off feature)
+    h_o, _, _, _ = orc.bundle_measure(mu_o, ocam, 0, False, False)
+    pix = h_o.reshape(L, 2) + 2.0 * rng.standard_normal((L, 2))
+    pix[5] += 400.0
+    pix[11] -= 350.0
+    y_pot = pix.T.copy()                                         # 2 x L, column j from matches[j]
+
+    # ---- data association (src/SLAM.cpp:387-396) ----
+    s_g, idx_g = api.snn(ctx, gcam, mu_g, S_g, y_pot)
+    s_o, idx_o = orc.snn(mu_o, S_o, y_pot, ocam, 0, False)
+    assert idx_g.tolist() == idx_o.tolist()
+    assert abs(s_g - s_o) <= 1e-9 * abs(s_o)
+    assert idx_g[5] != 5 and idx_g[11] != 11                     # the displaced features are not taken by their landmarks
+
+    # ---- landmark bookkeeping (src/SLAM.cpp:399-444): visible where associated; drop one bad landmark ----
+    visible = (idx_g >= 0).astype(np.uint8)
+    y = np.zeros(2 * L)
+    for j in range(L):
+        if idx_g[j] >= 0:
+            y[2 * j: 2 * j + 2] = y_pot[:, idx_g[j]]
+    drop = 5
+    mu_g, S_g = api.remove_landmark(ctx, mu_g, S_g, drop)
+    mu_o, S_o = orc.remove_landmark(mu_o, S_o, drop)
+    assert rel_err(mu_g, mu_o) < 1e-9
+    assert rel_err(_signed(S_g), _signed(S_o)) < 1e-9
+    keep = [j for j in range(L) if j != drop]
+    visible, y = visible[keep], y.reshape(L, 2)[keep].ravel()
+
+    # ---- measurement update (src/SLAM.cpp:489-495) ----
+    ctx.set_trs_solver(api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
+    try:
+        ret_g, mup_g, Sp_g, it_g, ev_g = api.measurement_update_iekf(ctx, gcam, mu_g, S_g, y, visible, 7.0)
+    finally:
+        ctx.set_trs_solver(api.TRS_EIG)
+    ret_o, mup_o, Sp_o, it_o, ev_o = orc.measurement_update_iekf(mu_o, S_o, y, visible, ocam, 7.0)
+    assert (ret_g, it_g, ev_g) == (ret_o, it_o, ev_o)
+    scale = np.maximum(np.abs(mup_o), 1e-3)
+    assert np.max(np.abs(mup_g - mup_o) / scale) <= 1e-7
+    assert rel_err(Sp_g.T @ Sp_g, Sp_o.T @ Sp_o) <= 1e-7
+    assert not np.tril(Sp_g, -1).any()

@@ -65,9 +65,9 @@ def main():
     with open(os.path.join(DST, "traffic_point_loglik.json"), "w") as f:
         json.dump(traffic, f, indent=1)
 
-    sq = counters(os.path.join(SRC, "corner_sq", "sq_results.db"), ["corner_tile_kernel"])
-    with open(os.path.join(DST, tag + "_corner_tile_sq_counters.json"), "w") as f:
-        json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT "
+    sq = counters(os.path.join(SRC, "corner_sq", "sq_results.db"), ["corner_strip_kernel", "corner_tile_kernel"])
+    with open(os.path.join(DST, tag + "_corner_sq_counters.json"), "w") as f:
+        json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU "
                               "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- python3 tools/run_corner.py 64 3",
                    "workload": "64 frames 1920x1080, both detectors", "mean_per_launch": sq}, f, indent=1)
     mf_db = os.path.join(SRC, "qr_mfma", "mfma_results.db")
