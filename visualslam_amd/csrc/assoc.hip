@@ -5,12 +5,14 @@
 // The reference re-factors SYY(:, columns of the associated landmarks) by Householder QR for every
 // (landmark j, candidate feature i) pair.  All candidates of landmark j share that column set, and the
 // set only ever grows at its right end (landmarks are visited in increasing order), so the factor is
-// kept incrementally here: the reflectors of the columns accepted so far (V, compact-WY T) are applied
-// to landmark j's two columns once, giving r12 (coupling to the earlier columns) and the 2 x 2
-// triangle r22; for candidate i only the last two entries of z = SA^-T (yA - muA) change:
+// kept incrementally here, right-looking: when a landmark is associated its two reflectors are applied
+// at once to the columns of every later landmark in a working copy of SYY, so that when landmark j's
+// turn comes its two columns already hold r12 (coupling to the earlier columns, rows < k) and the
+// part the two new reflectors act on; for candidate i only the last two entries of
+// z = SA^-T (yA - muA) change:
 //     z_last(i) = r22^-T (y_i - muY_j - r12^T z_prev),   dM2(i) = |z_prev|^2 + |z_last(i)|^2.
-// Same arithmetic as a from-scratch Householder factorisation (the signs of the rows of SA do not
-// enter |z| or log|diag|), O(N k) per landmark instead of O(m N k^2).
+// Same arithmetic as a from-scratch Householder factorisation in LAPACK's column order (the signs of
+// the rows of SA do not enter |z| or log|diag|), O(N (n - j)) per landmark instead of O(m N k^2).
 //
 // The reference builds the list of still-unassigned features with std::set_difference on a range
 // that is not sorted (src/dataAssociation.cpp:106); the walk is restated literally (a feature is
@@ -36,7 +38,7 @@ struct AssocArgs {
     int32_t *idx; size_t s_idx;          // [n] out (mode 0) / in (mode 1)
     double *s_out;                       // [batch] surprisal
     int32_t *jc_out;                     // [batch] (mode 1) joint compatibility
-    double *ws; size_t s_ws;             // per instance: V[N*N] T[N*N] z[N] a[2N] b[2N] w[2N] u[2N] t[2N]
+    double *ws; size_t s_ws;             // per instance: W[N*N] z[N] a[2N] b[2N]
     uint8_t *avail; size_t s_av;         // [m]
     int vec_lds;                         // work vectors in LDS instead of ws (set by assoc_launch)
 };
@@ -89,40 +91,6 @@ __device__ void apply_reflector(const double *x, double tau, int k0, int N, doub
 }
 
 
-constexpr int RG = 8;                    // columns a wave handles at once (independent loads in flight)
-
-// out0[c] = Vm(:, c)^T x0, out1[c] = Vm(:, c)^T x1 over rows [lo(c), hi(c)) for c in [0, kcols):
-// lo = (from_diag ? c : row_lo), hi = (to_diag ? c + 1 : row_hi).  Each wave takes RG columns at a time.
-__device__ __forceinline__ void wave_dots(const double *Vm, int N, int kcols, const double *x0, const double *x1,
-                                          bool from_diag, int row_lo, bool to_diag, int row_hi, double *out0, double *out1)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c0 = wave * RG; c0 < kcols; c0 += (AT / 64) * RG) {
-        double d0[RG], d1[RG];
-#pragma unroll
-        for (int q = 0; q < RG; ++q) { d0[q] = 0.0; d1[q] = 0.0; }
-        const int cl = min(c0 + RG, kcols) - 1;                        // last column of the group
-        const int rbeg = from_diag ? c0 : row_lo, rend = to_diag ? cl + 1 : row_hi;
-        for (int r = rbeg + lane; r < rend; r += 64) {
-            const double a0 = x0[r], a1 = x1 ? x1[r] : 0.0;
-            double vv[RG];
-#pragma unroll
-            for (int q = 0; q < RG; ++q) {
-                const int c = c0 + q;
-                const bool in = c < kcols && r >= (from_diag ? c : row_lo) && r < (to_diag ? c + 1 : row_hi);
-                vv[q] = in ? Vm[(size_t)c * N + r] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < RG; ++q) { d0[q] += vv[q] * a0; d1[q] += vv[q] * a1; }
-        }
-#pragma unroll
-        for (int q = 0; q < RG; ++q) {
-            for (int off = 32; off >= 1; off >>= 1) { d0[q] += __shfl_xor(d0[q], off, 64); d1[q] += __shfl_xor(d1[q], off, 64); }
-            if (lane == 0 && c0 + q < kcols) { out0[c0 + q] = d0[q]; if (out1) out1[c0 + q] = d1[q]; }
-        }
-    }
-}
-
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
@@ -134,48 +102,30 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     const int n = a.n, N = 2 * n, m = a.m;
     const double *muY = a.muY + inst * a.s_mu, *SYY = a.SYY + inst * a.s_S, *y = a.y + inst * a.s_y;
     int32_t *idx = a.idx + inst * a.s_idx;
-    extern __shared__ double vecs[];         // the 11 N doubles of work vectors when they fit (a.vec_lds)
-    double *V = a.ws + inst * a.s_ws, *T = V + (size_t)N * N, *z = a.vec_lds ? vecs : T + (size_t)N * N;
-    double *ca = z + N, *cb = ca + 2 * N, *w = cb + 2 * N, *u = w + 2 * N, *tv = u + 2 * N;
+    extern __shared__ double vecs[];         // the 5 N doubles of work vectors when they fit (a.vec_lds)
+    double *W = a.ws + inst * a.s_ws;        // working copy of SYY (N x N, ld N): accepted reflectors already applied
+    double *z = a.vec_lds ? vecs : W + (size_t)N * N;
+    double *ca = z + N, *cb = ca + 2 * N;
     uint8_t *avail = a.avail + inst * a.s_av;
     const double halflog2pi = log(3.14159265358979323846264338327950288 * 2) / 2;
 
     int k = 0, nA = 0;                       // accepted reflectors / associated landmarks
     int cursor = 0;                          // state of the offer-list walk (mode 0)
-    if (a.mode == 0) {
+    if (a.mode == 0)
         for (int i = tid; i < m; i += AT) avail[i] = 1;
-        __syncthreads();
-    }
+    for (size_t e = tid; e < (size_t)N * N; e += AT) W[e] = SYY[(e / N) * a.ldS + (e % N)];
+    __syncthreads();
     double zz = 0.0, logdet = 0.0, s = n * a.sU;
     for (int j = 0; j < n; ++j) {
         const int given = a.mode == 1 ? idx[j] : -2;
         if (a.mode == 1 && given == -1) continue;
-        // ---- landmark j's two columns through the accepted reflectors: ca = (I - V T V^T)^T SYY(:, 2j:2j+2) ----
+        // ---- landmark j's two columns: ca from the working copy (the accepted reflectors are in), cb untouched ----
         for (int r = tid; r < 2 * N; r += AT) {
-            const double v = SYY[(size_t)(2 * j + r / N) * a.ldS + (r % N)];
-            ca[r] = v; cb[r] = v;
+            const int q = r / N, rr = r % N;
+            ca[r] = W[(size_t)(2 * j + q) * N + rr];
+            cb[r] = SYY[(size_t)(2 * j + q) * a.ldS + rr];
         }
         __syncthreads();
-        if (k > 0) {
-            wave_dots(V, N, k, ca, ca + N, true, 0, false, N, w, w + N);      // w = V^T ca  (v_c is zero above row c)
-            __syncthreads();
-            wave_dots(T, N, k, w, w + N, false, 0, true, 0, u, u + N);       // u = T^T w   (T upper triangular)
-            __syncthreads();
-            for (int r = tid; r < 2 * N; r += AT) {                 // ca -= V u
-                const int q = r / N, rr = r % N;
-                double acc = 0.0;
-                // uniform trip count (v_c is stored with its zeros above row c), 16 independent loads per step
-                for (int c0 = 0; c0 < k; c0 += 16) {
-                    double vv[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) vv[e] = (c0 + e < k) ? V[(size_t)(c0 + e) * N + rr] : 0.0;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc += vv[e] * ((c0 + e < k) ? u[q * N + c0 + e] : 0.0);
-                }
-                ca[r] -= acc;
-            }
-            __syncthreads();
-        }
         // ---- two new reflectors on rows k.. (joint factor) ----
         double tau0, tau1;
         const double beta0 = make_reflector(ca, k, N, red, &tau0);
@@ -257,30 +207,44 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
             if (tid == 0) idx[j] = best_i;
         }
         if (best_i < 0) { __syncthreads(); continue; }
-        // ---- commit: V, T, z, running sums grow by two ----
-        for (int q = 0; q < 2; ++q) {
-            const int kk = k + q;
-            const double tau = q == 0 ? tau0 : tau1;
-            const double *src = ca + q * N;
-            double *vc = V + (size_t)kk * N;
-            for (int r = tid; r < N; r += AT) vc[r] = r < kk ? 0.0 : (r == kk ? 1.0 : src[r]);
-            __syncthreads();
-            wave_dots(V, N, kk, vc, nullptr, false, kk, false, N, tv, nullptr);   // tv = V(:, 0:kk)^T v  (v is zero above row kk)
-            __syncthreads();
-            double *tc = T + (size_t)kk * N;
-            for (int r = tid; r < kk; r += AT) {                    // T(0:kk, kk) = -tau T(0:kk,0:kk) tv
-                double acc = 0.0;
-                for (int l0 = r & ~15; l0 < kk; l0 += 16) {         // T is upper triangular: columns l >= r of row r
-                    double tt[16];
+        // ---- commit: the two reflectors go into every later landmark's columns; z and the running sums grow by two.
+        // v0 = [1 at k; ca(k+1..)], v1 = [1 at k+1; ca(N + k+2..)].  With s01 = v1^T v0 both act in one read pass
+        // and one update pass per column:  a -= tau0 d0 v0 + tau1 (e1 - tau0 d0 s01) v1,  d0 = v0^T a, e1 = v1^T a. ----
+        {
+            double ps = (tid == 0 && k + 1 < N) ? ca[k + 1] : 0.0;                       // v1(k+1) = 1 times v0(k+1)
+            for (int r = k + 2 + tid; r < N; r += AT) ps += ca[r] * ca[N + r];
+            const double s01 = wg_sum(ps, red);
+            constexpr int CG = 4;                                                        // columns a wave handles at once
+            for (int c0 = 2 * (j + 1) + wave * CG; c0 < N; c0 += (AT / 64) * CG) {
+                double d0[CG], e1[CG];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { const int l = l0 + e; tt[e] = (l >= r && l < kk) ? T[(size_t)l * N + r] : 0.0; }
+                for (int q = 0; q < CG; ++q) { d0[q] = 0.0; e1[q] = 0.0; }
+                for (int r = k + lane; r < N; r += 64) {
+                    const double v0 = (r == k) ? 1.0 : ca[r];
+                    const double v1 = (r == k) ? 0.0 : ((r == k + 1) ? 1.0 : ca[N + r]);
+                    double av[CG];
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { const int l = l0 + e; acc += tt[e] * ((l >= r && l < kk) ? tv[l] : 0.0); }
+                    for (int q = 0; q < CG; ++q) av[q] = (c0 + q < N) ? W[(size_t)(c0 + q) * N + r] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) { d0[q] += v0 * av[q]; e1[q] += v1 * av[q]; }
                 }
-                tc[r] = -tau * acc;
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    for (int off = 32; off >= 1; off >>= 1) { d0[q] += __shfl_xor(d0[q], off, 64); e1[q] += __shfl_xor(e1[q], off, 64); }
+                    d0[q] *= tau0;
+                    e1[q] = tau1 * (e1[q] - d0[q] * s01);
+                }
+                for (int r = k + lane; r < N; r += 64) {
+                    const double v0 = (r == k) ? 1.0 : ca[r];
+                    const double v1 = (r == k) ? 0.0 : ((r == k + 1) ? 1.0 : ca[N + r]);
+                    double av[CG];
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) av[q] = (c0 + q < N) ? W[(size_t)(c0 + q) * N + r] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < CG; ++q)
+                        if (c0 + q < N) W[(size_t)(c0 + q) * N + r] = av[q] - (d0[q] * v0 + e1[q] * v1);
+                }
             }
-            if (tid == 0) tc[kk] = tau;
-            __syncthreads();
         }
         if (tid == 0) { z[k] = best_z0; z[k + 1] = best_z1; }
         zz += best_z0 * best_z0 + best_z1 * best_z1;
@@ -368,14 +332,14 @@ double chi2inv_host(double p, double nu)
 
 double normcdf_host(double z) { return 0.5 * std::erfc(-z / std::sqrt(2.0)); }
 
-size_t assoc_ws_doubles(int n) { const size_t N = 2 * (size_t)n; return 2 * N * N + 11 * N + 64; }
+size_t assoc_ws_doubles(int n) { const size_t N = 2 * (size_t)n; return N * N + 5 * N + 64; }
 
 // Queues the association kernel for `batch` instances; every pointer is device memory.
 vslam_status assoc_launch(vslam_ctx *ctx, AssocArgs a, int batch)
 {
-    // The work vectors (z, two column pairs, w, u, t: 11 N doubles) live in LDS when they fit: every phase
+    // The work vectors (z and two column pairs: 5 N doubles) live in LDS when they fit: every phase
     // boundary is then an LDS round trip instead of one through L2.
-    const size_t vec_bytes = (size_t)11 * 2 * a.n * sizeof(double);
+    const size_t vec_bytes = (size_t)5 * 2 * a.n * sizeof(double);
     a.vec_lds = vec_bytes <= 144 * 1024;
     const size_t lds = a.vec_lds ? vec_bytes : 0;
     if (lds > 48 * 1024)
