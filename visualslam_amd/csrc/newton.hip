@@ -24,64 +24,96 @@ namespace vslam {
 
 constexpr int CB = 64;           // Cholesky block
 
-// Upper Cholesky of the jb x jb diagonal block at (j0, j0), one wave, in LDS: row k of U from the
-// rows above it, lane j owning column j:  U[k][j] = (A[k][j] - sum_{l<k} U[l][k] U[l][j]) / U[k][k].
-// Only the upper triangle is read and written.  A non-positive pivot stores its 1-based column in
-// *info (first one wins); the arithmetic carries on with NaNs.
-constexpr int CLD = CB + 1;
+// Upper Cholesky of the jb x jb diagonal block at (j0, j0) by one wave, the block in LDS, lane j owning
+// column j.  Rows are finished eight at a time: the eight rows first receive all finished rows above
+// them (left-looking; per finished row one own-column read and eight broadcast reads feed eight
+// multiply-adds held in registers), then are factored among themselves with lane broadcasts.  Only the
+// upper triangle is read and written.  A non-positive pivot stores its 1-based column in *info (first
+// one wins); the arithmetic carries on with NaNs.
+constexpr int PLD = CB + 2;      // even: the eight broadcast values of a row are two aligned 16-byte pairs apart
+constexpr int PR = 8;
+__device__ __forceinline__ double readlane_f64(double v, int l)   // v of lane l (wave-uniform l) as a wave-uniform value
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info)
 {
-    __shared__ double U[CB * CLD];
+    __shared__ __align__(16) double U[CB * PLD];                  // U[l][j] at l * PLD + j
     const int lane = threadIdx.x;
     for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
         double v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = (lane <= cb + j && cb + j < jb) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
+        for (int j = 0; j < 16; ++j)
+            v[j] = (lane <= cb + j && cb + j < jb) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : ((lane == cb + j) ? 1.0 : 0.0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) U[lane * CLD + cb + j] = v[j];
+        for (int j = 0; j < 16; ++j) U[lane * PLD + cb + j] = v[j];
     }
     __syncthreads();
-    for (int k = 0; k < jb; ++k) {
-        const double num = lds_dot_sub(U[k * CLD + lane], U + k, CLD, U + lane, CLD, 0, k);
-        const double dkk = __shfl(num, k, 64);
-        if (lane == k && !(dkk > 0.0)) atomicCAS(info, 0, j0 + k + 1);
-        const double d = sqrt(dkk);
-        __syncthreads();
-        if (lane >= k) U[k * CLD + lane] = (lane == k) ? d : num / d;
-        __syncthreads();
+    bool bad = false;
+    for (int kb = 0; kb < CB; kb += PR) {
+        double acc[PR];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
+#pragma unroll 4
+        for (int l = 0; l < kb; ++l) {
+            const double own = U[l * PLD + lane];
+            const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb);
+            const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+            acc[0] -= b0.x * own; acc[1] -= b0.y * own; acc[2] -= b1.x * own; acc[3] -= b1.y * own;
+            acc[4] -= b2.x * own; acc[5] -= b2.y * own; acc[6] -= b3.x * own; acc[7] -= b3.y * own;
+        }
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const int row = kb + r;
+            const double dkk = readlane_f64(acc[r], row);
+            if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
+            const double d = sqrt(dkk);
+            const double u = (lane == row) ? d : acc[r] / d;     // row `row` of U (meaningful for lanes >= row)
+            U[row * PLD + lane] = u;
+#pragma unroll
+            for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
+        }
     }
+    __syncthreads();
 #pragma unroll 8
     for (int c = 0; c < jb; ++c)
-        if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * CLD + c];
+        if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * PLD + c];
 }
 
 // Row panel of the factor: X = U_JJ^-T * A[J, rest] in place.  A workgroup (one wave) owns 64
-// columns; lane = column, forward substitution x_k = (b_k - sum_{l<k} U[l][k] x_l) / U[k][k] with
-// both operands in LDS.
+// columns; lane = column with its 64 entries in registers, forward substitution
+// x_k = (b_k - sum_{l<k} U[l][k] x_l) / U[k][k] with U read from LDS (the same address in every lane).
+constexpr int CLD = CB + 2;
 __global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int n, int j0)
 {
-    extern __shared__ double potrf_lds[];
-    double *U = potrf_lds;                 // [CB][CLD]
-    double *X = potrf_lds + CB * CLD;      // [CB][CLD], X[k][col]
+    __shared__ __align__(16) double Ut[CB * CLD];                 // Ut[k][l] = U[l][k]: column k contiguous in l
     const int lane = threadIdx.x;
     const int c0 = j0 + CB + blockIdx.x * CB, nc = min(CB, n - c0);
-    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 32 in flight
-        double u[16], x[16];
+    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
+        double u[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            u[j] = (lane <= cb + j) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
-            x[j] = (cb + j < nc) ? A[(size_t)(c0 + cb + j) * lda + j0 + lane] : 0.0;
-        }
+        for (int j = 0; j < 16; ++j) u[j] = (lane <= cb + j) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { U[lane * CLD + cb + j] = u[j]; X[lane * CLD + cb + j] = x[j]; }
+        for (int j = 0; j < 16; ++j) Ut[(cb + j) * CLD + lane] = u[j];
     }
+    double x[CB];
+    double *colx = A + (size_t)(c0 + (lane < nc ? lane : 0)) * lda + j0;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) x[k] = colx[k];
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < CB; ++k) {
-        X[k * CLD + lane] = lds_dot_sub(X[k * CLD + lane], U + k, CLD, X + lane, CLD, 0, k) / U[k * CLD + k];
+        double s = x[k];
+#pragma unroll
+        for (int l = 0; l < k; ++l) s -= Ut[k * CLD + l] * x[l];
+        x[k] = s / Ut[k * CLD + k];
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int c = 0; c < nc; ++c) A[(size_t)(c0 + c) * lda + j0 + lane] = X[lane * CLD + c];
+    if (lane < nc) {
+#pragma unroll
+        for (int k = 0; k < CB; ++k) colx[k] = x[k];
+    }
 }
 
 __global__ void add_diag_kernel(double *A, int lda, int n, double lam)
@@ -101,14 +133,12 @@ __global__ void zero_below_diag_kernel(double *A, int lda, int n)
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info)
 {
     hipStream_t s = ctx->stream;
-    const size_t lds = (size_t)2 * CB * CLD * 8;
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
         hipLaunchKernelGGL(potf2_upper_kernel, dim3(1), dim3(64), 0, s, A, lda, j0, jb, info);
         const int rest = n - j0 - jb;
         if (rest <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB), dim3(64), lds, s, A, lda, n, j0);
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB), dim3(64), 0, s, A, lda, n, j0);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         GemmDesc g;                                   // A[rest, rest] -= X^T X
         g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0;
