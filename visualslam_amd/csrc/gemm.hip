@@ -25,7 +25,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int BK = 16;
 
 struct GemmArgs {
-    int M, N, K, lda, ldb, ldc, amode, b_upper, kchunk, tilesM;
+    int M, N, K, lda, ldb, ldc, amode, b_upper, kchunk, tilesM, c_upper;
     double alpha, beta;
     const double *A, *B;
     double *C;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_m = blockIdx.x % g.tilesM, tile_n = blockIdx.x / g.tilesM;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (g.c_upper && m0 > n0 + BN - 1) return;             // tile entirely below the diagonal of C: not wanted
     const int split = blockIdx.y, b = blockIdx.z;
     const double *A = g.A + (size_t)b * g.sA;
     const double *B = g.B + (size_t)b * g.sB;
@@ -167,7 +168,7 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream)
     if (d.ksplit < 1 || d.batch > 65535 || d.ksplit > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "gemm: bad split/batch");
     GemmArgs a;
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc;
-    a.amode = (int)d.amode; a.b_upper = d.b_upper ? 1 : 0;
+    a.amode = (int)d.amode; a.b_upper = d.b_upper ? 1 : 0; a.c_upper = d.c_upper ? 1 : 0;
     a.alpha = d.alpha; a.beta = d.beta; a.A = d.A; a.B = d.B; a.C = d.C;
     a.sA = d.strideA; a.sB = d.strideB; a.sC = d.strideC; a.sSplit = d.strideSplit;
     int kchunk = (d.K + d.ksplit - 1) / d.ksplit;

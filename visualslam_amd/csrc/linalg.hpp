@@ -40,6 +40,7 @@ struct GemmDesc {
     bool transA, transB;     // op(A) is M x K, op(B) is K x N
     AMode amode = A_PLAIN;   // applies to the stored A matrix coordinates
     bool b_upper = false;    // stored B is upper triangular (reads 0 below the diagonal)
+    bool c_upper = false;    // only the tiles of C that touch its upper triangle are computed and written
     double alpha = 1.0, beta = 0.0;
     const double *A; int lda; size_t strideA = 0;
     const double *B; int ldb; size_t strideB = 0;

@@ -140,8 +140,8 @@ vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *inf
         if (rest <= 0) break;
         hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB), dim3(64), 0, s, A, lda, n, j0);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        GemmDesc g;                                   // A[rest, rest] -= X^T X
-        g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0;
+        GemmDesc g;                                   // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
+        g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0; g.c_upper = true;
         g.A = A + (size_t)(j0 + jb) * lda + j0; g.lda = lda;
         g.B = g.A; g.ldb = lda;
         g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda;
