@@ -28,7 +28,9 @@ struct vslam_ctx {
     std::vector<vslam_pending_copy> pending;
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose barrier gave up
+    int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up; [64..320) ready
+                                 // marks of the chained triangular solve (value = chain_epoch of the call)
+    int chain_epoch = 0;
     int *flags_host = nullptr;   // pinned mirror read by stream_finish
     int trs_solver = 0;          // VSLAM_TRS_EIG (default) / VSLAM_TRS_CHOLESKY
     int trs_last = -1;           // route the last measurement update took (-1: none yet)

@@ -198,8 +198,8 @@ static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VSLAM_ERR_DEVICE; }
         c->own_stream = true;
     }
-    if (hipMalloc(reinterpret_cast<void **>(&c->flags), 64 * sizeof(int)) != hipSuccess ||
-        hipMemset(c->flags, 0, 64 * sizeof(int)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void **>(&c->flags), 320 * sizeof(int)) != hipSuccess ||
+        hipMemset(c->flags, 0, 320 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         vslam_ctx_destroy(c);
         return VSLAM_ERR_ALLOC;

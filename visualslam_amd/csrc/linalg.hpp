@@ -8,6 +8,13 @@
 
 namespace vslam {
 
+// v of lane l (l wave-uniform) as a wave-uniform value: two v_readlane, no LDS round trip.
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 #ifdef __HIPCC__
 // acc - sum_{l in [l0, l1)} a[l * sa] * b[l * sb] with the loads of eight terms in flight at a time
 // (the callers run one wave per workgroup, so nothing else hides the LDS latency).

@@ -32,12 +32,6 @@ constexpr int CB = 64;           // Cholesky block
 // one wins); the arithmetic carries on with NaNs.
 constexpr int PLD = CB + 2;      // even: the eight broadcast values of a row are two aligned 16-byte pairs apart
 constexpr int PR = 8;
-__device__ __forceinline__ double readlane_f64(double v, int l)   // v of lane l (wave-uniform l) as a wave-uniform value
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 __global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info)
 {
     __shared__ __align__(16) double U[CB * PLD];                  // U[l][j] at l * PLD + j

@@ -116,15 +116,19 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
     __syncthreads();
     if (tid < 64) {
         double v = (tid < ib) ? z[i0 + tid] : 0.0;
+        // substitution with the running right-hand side in the lanes; the pivot lane's value and the
+        // reciprocal of its diagonal entry are broadcast with v_readlane (the chain per step is
+        // readlane -> multiply -> multiply-add)
+        const double rinv = 1.0 / U[tid][tid];                      // rows past ib hold a zero diagonal: unused
         if (trans) {
             for (int k = 0; k < ib; ++k) {
-                const double xk = __shfl(v, k, 64) / U[k][k];
+                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
                 if (tid > k) v -= U[k][tid] * xk;
                 else if (tid == k) v = xk;
             }
         } else {
             for (int k = ib - 1; k >= 0; --k) {
-                const double xk = __shfl(v, k, 64) / U[k][k];
+                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
                 if (tid < k) v -= U[tid][k] * xk;
                 else if (tid == k) v = xk;
             }
@@ -151,11 +155,99 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
     }
 }
 
+// The same solve in ONE launch for up to TC_MAX diagonal blocks: workgroup i owns the i-th block in
+// dependency order (trans: first to last; otherwise last to first).  It adds up the contributions of the
+// blocks before it as their solutions appear (coefficients are fetched ahead of the wait: they do not
+// depend on it), solves its own 64 x 64 block in one wave and publishes the 64 entries followed by a
+// ready mark.  Only the chain of diagonal solves is sequential; the off-diagonal work of all
+// workgroups overlaps it.  All workgroups are resident together (TC_MAX <= 240 of 256 threads), a wait
+// that exceeds its bound raises *err and lets every wave run to the end.
+constexpr int TC_MAX = 240;
+__global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n, int ldS, int trans, double *z, int *ready, int epoch, int *err)
+{
+    __shared__ double U[TBK][TBK + 1];
+    __shared__ double part[4][TBK];
+    const int tid = threadIdx.x, c = tid & 63, p = tid >> 6;
+    const int nblk = (n + TBK - 1) / TBK;
+    const int w = trans ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int i0 = w * TBK, ib = min(TBK, n - i0);
+    {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = tid + 256 * j, r = idx % TBK, cc = idx / TBK;
+            v[j] = (r <= cc && cc < ib) ? S[(size_t)(i0 + cc) * ldS + i0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = tid + 256 * j;
+            U[idx % TBK][idx / TBK] = v[j];
+        }
+    }
+    const double rhs = (tid < ib) ? z[i0 + tid] : 0.0;          // own right-hand side: fetched before any waiting
+    // thread (c, p): own entry c, entries 16p..16p+15 of the other block
+    double acc = 0.0;
+    bool dead = false;
+    for (int s = 0; s < (int)blockIdx.x; ++s) {
+        const int v = trans ? s : nblk - 1 - s;
+        const int v0 = v * TBK;                                   // the last block may be short: entries j >= n are skipped
+        double coef[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = v0 + 16 * p + e;
+            // trans: U(j, i0 + c)  (rows of the earlier block, own column);  otherwise U(i0 + c, j)
+            coef[e] = (c < ib && j < n) ? (trans ? S[(size_t)(i0 + c) * ldS + j] : S[(size_t)j * ldS + i0 + c]) : 0.0;
+        }
+        unsigned spins = 0;
+        while (!dead && __hip_atomic_load(&ready[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            if ((++spins & 255u) == 0) {
+                if (spins > (1u << 22)) atomicExch(err, 1);
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (v0 + 16 * p + e < n) acc += coef[e] * __hip_atomic_load(&z[v0 + 16 * p + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    part[p][c] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        double v = (tid < ib) ? rhs - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) : 0.0;
+        // substitution with the running right-hand side in the lanes; the pivot lane's value and the
+        // reciprocal of its diagonal entry are broadcast with v_readlane (the chain per step is
+        // readlane -> multiply -> multiply-add)
+        const double rinv = 1.0 / U[tid][tid];                      // rows past ib hold a zero diagonal: unused
+        if (trans) {
+            for (int k = 0; k < ib; ++k) {
+                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
+                if (tid > k) v -= U[k][tid] * xk;
+                else if (tid == k) v = xk;
+            }
+        } else {
+            for (int k = ib - 1; k >= 0; --k) {
+                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
+                if (tid < k) v -= U[tid][k] * xk;
+                else if (tid == k) v = xk;
+            }
+        }
+        if (tid < ib) __hip_atomic_store(&z[i0 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid == 0) __hip_atomic_store(&ready[w], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z)
 {
     hipStream_t s = ctx->stream;
     if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     const int nblk = (n + TBK - 1) / TBK;
+    if (nblk > 1 && nblk <= TC_MAX) {
+        ctx->chain_epoch = ctx->chain_epoch == 0x7fffffff ? 1 : ctx->chain_epoch + 1;
+        hipLaunchKernelGGL(trsv_chain_kernel, dim3(nblk), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, z, ctx->flags + 64, ctx->chain_epoch, ctx->flags);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        return VSLAM_OK;
+    }
     for (int step = 0; step < nblk; ++step) {
         const int blk = trans ? step : nblk - 1 - step;
         const int i0 = blk * TBK, ib = (n - i0) < TBK ? (n - i0) : TBK;
