@@ -55,7 +55,7 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
         "metric": "corner-detect frames/s (1080p)", "value": F * args.steps * world / elapsed, "unit": "frames/s",
         "frames_per_gpu_per_step": F, "ms_per_step": elapsed / args.steps * 1e3,
         "mean_keypoints_per_frame": {"harris": float(counts[:, 0].mean()), "shi_tomasi": float(counts[:, 1].mean())},
-        "roofline": {"bound": "hbm", "kernel": "corner_tile_kernel<3,false> + sort/merge/emit", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "corner_strip_kernel<3> + sort/merge/emit", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_step": alg, "device_ms_per_step": dev_ms},
         "dtype": "u8 -> int32 structure tensor -> f32 response",
