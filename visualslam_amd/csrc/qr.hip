@@ -9,16 +9,17 @@
 //   value (tau = 0).  So R carries the same signs as the reference's.
 //
 // Per 32-column panel:
-//   qr_panel_kernel   one workgroup per matrix factors the m x 32 panel
-//                     left-looking: column c receives the previous reflectors
-//                     in compact-WY form (two passes over the panel's finished
-//                     columns, one 32-value workgroup reduction each), then its
-//                     own reflector is formed; T (32x32) is built on the fly.
-//   gemm (MFMA)       W = V^T A2, split over K so the skinny product fills the chip
-//   qr_apply_t_kernel W2 = T^T * sum(W slabs)
-//   gemm (MFMA)       A2 -= V W2
-// V is read straight out of the factored panel (unit diagonal and zeros above
-// it are synthesised by the GEMM's operand loader).
+//   panel factorisation   qr_panel_coop_kernel: the panel lives in the LDS of one workgroup (<= 512
+//                         rows, any batch) or of G co-resident workgroups that exchange one vector
+//                         per column (taller panels, batch <= 8); right-looking, T from V^T V at
+//                         the end.  qr_panel_kernel (one workgroup per matrix, left-looking from
+//                         global memory) remains for tall panels in large batches.
+//   gemm (MFMA)           W = V^T A2, split over K so the skinny product fills the chip
+//   qr_block_solve_kernel W2 = T^T * sum(W slabs)
+//   gemm (MFMA)           A2 -= V W2
+// V is read straight out of the factored panel (unit diagonal and zeros above it are synthesised by
+// the GEMM's operand loader).  One wide matrix additionally groups four panels into a 128-column
+// block whose far updates run on a side stream (see qr_outer_block).
 #include "linalg.hpp"
 #include <cstdlib>
 
