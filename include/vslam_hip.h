@@ -230,10 +230,13 @@ vslam_status vslam_time_update(vslam_ctx *ctx, const double *mu, const double *S
                                const double *pos_tune, const double *ori_tune, double dt,
                                double *mu_out, double *S_out, int ldSout);
 /* Device-pointer batch of independent filters: mu + b*n, S + b*n*n (ld n), same for the outputs.
- * pos_tune / ori_tune are host pointers.  Queued on the context's stream, not synchronised. */
+ * pos_tune / ori_tune are host pointers.  s_is_upper != 0: the caller guarantees that every S is upper
+ * triangular, as every factor this library or the reference's QR returns is; its strict lower part is
+ * then not read and the structured O(n^2) kernels run (vslam_time_update checks this itself).
+ * Queued on the context's stream, not synchronised. */
 vslam_status vslam_time_update_batch_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int batch,
                                          const double *pos_tune, const double *ori_tune, double dt,
-                                         double *mu_out, double *S_out);
+                                         double *mu_out, double *S_out, int s_is_upper);
 
 /* ---- landmark removal ----
  * removeBadLandmarks(mup, Sp, landmarks, j), src/SLAM.cpp:796-820: the three states of landmark j leave

@@ -1,6 +1,7 @@
 """GPU parity of the time update (vslam_time_update*) against the CPU oracle's dense restatement of
 timeUpdateContinuous (reference src/gaussian.hpp:337-383).  The device path works on the 12-state
-RK4 block and an (n + 6) x n QR; the oracle does the reference's full n x (2n + 1) recursion and the
+RK4 block and an (n + 6) x n QR -- structured O(n^2) kernels for an upper-triangular factor, the
+blocked dense QR otherwise; the oracle does the reference's full n x (2n + 1) recursion and the
 3n x n QR.  Tolerance: 1e-9 relative (fp64).  Parity with the reference itself is unpinned: it has no
 test with numbers for this step."""
 import numpy as np
@@ -77,6 +78,53 @@ def test_errors(ctx):
         api.time_update(ctx, np.zeros(11), np.eye(11), PT, OT, 0.1)
     with pytest.raises(api.VslamError):
         api.time_update(ctx, np.zeros(15), np.eye(15), PT, OT, -1.0)
+
+
+def test_structured_and_dense_paths_agree(ctx):
+    """The same upper-triangular factors through both device paths (s_is_upper on / off), out of place."""
+    import torch
+    from visualslam_amd import api
+    B, L = 3, 60
+    n = 12 + 3 * L
+    xs, Ss = zip(*[_filter(L, 300 + b) for b in range(B)])
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(np.stack(xs), device=dev)
+    S = torch.tensor(np.stack([s.T for s in Ss]).copy(), device=dev)
+    outs = []
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    for upper in (True, False):
+        mo = torch.full_like(mu, float("nan"))
+        So = torch.full_like(S, float("nan"))                     # the lower triangle must be written too
+        api.time_update_batch_dev(tctx, mu, S, n, PT, OT, 0.04, mo, So, s_is_upper=upper)
+        torch.cuda.synchronize()
+        outs.append((mo.cpu().numpy(), So.cpu().numpy()))
+    tctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-12
+    assert not np.isnan(outs[0][1]).any()
+
+
+def test_structured_path_large_state(ctx):
+    """n = 1212 takes the per-panel launches of the structured path; checked through the covariance identity
+    P+ = Jx P Jx' + dt Jw Q Jw' restricted to the pose block and a few landmark entries, and against the dense path."""
+    import torch
+    from visualslam_amd import api
+    L = 400
+    n = 12 + 3 * L
+    x, S = _filter(L, 17)
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(x[None], device=dev)
+    St = torch.tensor(np.ascontiguousarray(S.T)[None], device=dev)
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    res = []
+    for upper in (True, False):
+        mo, So = torch.empty_like(mu), torch.empty_like(St)
+        api.time_update_batch_dev(tctx, mu, St, n, PT, OT, 1 / 30, mo, So, s_is_upper=upper)
+        torch.cuda.synchronize()
+        res.append(So[0].cpu().numpy().T)
+    tctx.close()
+    assert rel_err(res[0], res[1]) < 1e-11
+    assert not np.tril(res[0], -1).any()
 
 
 def test_batch_dev_in_place(ctx):

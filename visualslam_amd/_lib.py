@@ -108,7 +108,7 @@ def _declare(L):
         "vslam_snn_density_batch_dev": [_vp, _i, _vp, _sz, _vp, _i, _sz, _i, _vp, _sz, _i, _i, _i, _i, _vp, _vp],
         "vslam_snn": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp],
         "vslam_time_update": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _i],
-        "vslam_time_update_batch_dev": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp],
+        "vslam_time_update_batch_dev": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _i],
         "vslam_remove_landmark": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i],
         "vslam_match_hamming": [_vp, _vp, _i, _vp, _i, _i, _vp, _vp],
         "vslam_match_hamming_batch_dev": [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp, _i, _i, _vp, _vp],

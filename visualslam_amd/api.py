@@ -339,11 +339,12 @@ def snn_density_batch_dev(ctx, muY, SYY, y, n, m, width, height, idx, surprisal,
                                              int(height), int(enforce_jc), _tp(idx), _tp(surprisal)), ctx.ptr)
 
 
-def time_update_batch_dev(ctx, mu, S, n, pos_tune, ori_tune, dt, mu_out, S_out):
-    """torch tensors on the GPU: mu (B, n) f64, S (B, n, n) column-major per instance; outputs alike (may alias)."""
+def time_update_batch_dev(ctx, mu, S, n, pos_tune, ori_tune, dt, mu_out, S_out, s_is_upper=True):
+    """torch tensors on the GPU: mu (B, n) f64, S (B, n, n) column-major per instance; outputs alike (may alias).
+    s_is_upper: every S is upper triangular (structured kernels); False takes the dense QR."""
     pt, ot = _F(pos_tune), _F(ori_tune)
     check(ctx._L.vslam_time_update_batch_dev(ctx.ptr, _tp(mu), _tp(S), n, mu.shape[0], _p(pt), _p(ot), float(dt),
-                                             _tp(mu_out), _tp(S_out)), ctx.ptr)
+                                             _tp(mu_out), _tp(S_out), int(bool(s_is_upper))), ctx.ptr)
 
 
 def match_hamming_batch_dev(ctx, query, train, idx, dist=None, nt_each=None):
