@@ -99,6 +99,13 @@ def run_dense_leg(ctx, dev, stream):
     frame["match_hamming_64_frames_ms"] = mms
     frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
+    # a bank of independent filters on one GPU: one context (stream + workspace) per host thread
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from run_iekf_bank import bank_throughput
+    rate8, _ = bank_throughput(150, 8, 4, api.TRS_CHOLESKY, dev.index or 0)
+    upd["bank_8_contexts_updates_per_s"] = rate8
     return {
         "frame_steps_150_landmarks": frame,
         "qr": {"workload": "in-place Householder QR (R only), %d x %d fp64, device resident" % (n, n), "ms": ms,
