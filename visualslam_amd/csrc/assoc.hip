@@ -38,7 +38,7 @@ struct AssocArgs {
     int32_t *idx; size_t s_idx;          // [n] out (mode 0) / in (mode 1)
     double *s_out;                       // [batch] surprisal
     int32_t *jc_out;                     // [batch] (mode 1) joint compatibility
-    double *ws; size_t s_ws;             // per instance: W[N*N] z[N] a[2N] b[2N]
+    double *ws; size_t s_ws;             // per instance: W[N*N] z[N] a[2N] ind[3n] (2N reserved)
     uint8_t *avail; size_t s_av;         // [m]
     int vec_lds;                         // work vectors in LDS instead of ws (set by assoc_launch)
 };
@@ -91,6 +91,37 @@ __device__ void apply_reflector(const double *x, double tau, int k0, int N, doub
 }
 
 
+
+// R factor (r00, r01, r11) of the Householder QR of the two columns c0, c1 (N rows, N >= 2), by one wave;
+// LAPACK / Eigen reflector convention.  Nothing is stored besides the three numbers.
+__device__ __forceinline__ void wave_qr2(const double *c0, const double *c1, int N, double *r00, double *r01, double *r11)
+{
+    const int lane = threadIdx.x & 63;
+    double s00 = 0.0, s01 = 0.0;
+    for (int r = 1 + lane; r < N; r += 64) { const double x = c0[r]; s00 += x * x; s01 += x * c1[r]; }
+    for (int off = 32; off >= 1; off >>= 1) { s00 += __shfl_xor(s00, off, 64); s01 += __shfl_xor(s01, off, 64); }
+    const double alpha = c0[0];
+    double beta, tau, scale;
+    if (s00 <= 2.2250738585072014e-308) { beta = alpha; tau = 0.0; scale = 0.0; }
+    else {
+        beta = sqrt(alpha * alpha + s00);
+        if (alpha >= 0.0) beta = -beta;
+        scale = 1.0 / (alpha - beta);
+        tau = (beta - alpha) / beta;
+    }
+    const double d = tau * (c1[0] + scale * s01);                  // tau * v^T c1
+    double t11 = 0.0, a11 = 0.0;
+    for (int r = 1 + lane; r < N; r += 64) {
+        const double y = c1[r] - d * (scale * c0[r]);
+        if (r == 1) a11 = y; else t11 += y * y;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { t11 += __shfl_xor(t11, off, 64); a11 += __shfl_xor(a11, off, 64); }
+    double b1;
+    if (t11 <= 2.2250738585072014e-308) b1 = a11;
+    else { b1 = sqrt(a11 * a11 + t11); if (a11 >= 0.0) b1 = -b1; }
+    *r00 = beta; *r01 = c1[0] - d; *r11 = b1;
+}
+
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
@@ -105,7 +136,7 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     extern __shared__ double vecs[];         // the 5 N doubles of work vectors when they fit (a.vec_lds)
     double *W = a.ws + inst * a.s_ws;        // working copy of SYY (N x N, ld N): accepted reflectors already applied
     double *z = a.vec_lds ? vecs : W + (size_t)N * N;
-    double *ca = z + N, *cb = ca + 2 * N;
+    double *ca = z + N, *ind = ca + 2 * N;   // ind[3j..3j+2]: R factor of landmark j's two columns on their own
     uint8_t *avail = a.avail + inst * a.s_av;
     const double halflog2pi = log(3.14159265358979323846264338327950288 * 2) / 2;
 
@@ -114,17 +145,19 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     if (a.mode == 0)
         for (int i = tid; i < m; i += AT) avail[i] = 1;
     for (size_t e = tid; e < (size_t)N * N; e += AT) W[e] = SYY[(e / N) * a.ldS + (e % N)];
+    if (a.mode == 0)                          // individual factors (src/dataAssociation.cpp:165-171) do not depend on the search: all at once
+        for (int j = wave; j < n; j += AT / 64) {
+            double r00, r01, r11;
+            wave_qr2(SYY + (size_t)(2 * j) * a.ldS, SYY + (size_t)(2 * j + 1) * a.ldS, N, &r00, &r01, &r11);
+            if (lane == 0) { ind[3 * j] = r00; ind[3 * j + 1] = r01; ind[3 * j + 2] = r11; }
+        }
     __syncthreads();
     double zz = 0.0, logdet = 0.0, s = n * a.sU;
     for (int j = 0; j < n; ++j) {
         const int given = a.mode == 1 ? idx[j] : -2;
         if (a.mode == 1 && given == -1) continue;
-        // ---- landmark j's two columns: ca from the working copy (the accepted reflectors are in), cb untouched ----
-        for (int r = tid; r < 2 * N; r += AT) {
-            const int q = r / N, rr = r % N;
-            ca[r] = W[(size_t)(2 * j + q) * N + rr];
-            cb[r] = SYY[(size_t)(2 * j + q) * a.ldS + rr];
-        }
+        // ---- landmark j's two columns from the working copy (the accepted reflectors are in) ----
+        for (int r = tid; r < 2 * N; r += AT) ca[r] = W[(size_t)(2 * j) * N + r];
         __syncthreads();
         // ---- two new reflectors on rows k.. (joint factor) ----
         double tau0, tau1;
@@ -140,12 +173,7 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         int best_i = -1;
         const double scur = s;
         if (a.mode == 0) {
-            // ---- individual factor: QR of the two columns on their own (src/dataAssociation.cpp:165-171) ----
-            double ti0, ti1;
-            const double ib0 = make_reflector(cb, 0, N, red, &ti0);
-            apply_reflector(cb, ti0, 0, N, cb + N, red);
-            const double i01 = cb[N];
-            const double ib1 = make_reflector(cb + N, 1, N, red, &ti1);
+            const double ib0 = ind[3 * j], i01 = ind[3 * j + 1], ib1 = ind[3 * j + 2];   // individual factor
             // ---- features still on offer: avail[] holds the std::set_difference walk over idx[0..j), kept up
             //      to date as associations are made (see the end of the loop body) ----
             // ---- candidates ----
@@ -337,7 +365,7 @@ size_t assoc_ws_doubles(int n) { const size_t N = 2 * (size_t)n; return N * N + 
 // Queues the association kernel for `batch` instances; every pointer is device memory.
 vslam_status assoc_launch(vslam_ctx *ctx, AssocArgs a, int batch)
 {
-    // The work vectors (z and two column pairs: 5 N doubles) live in LDS when they fit: every phase
+    // The work vectors (z, one column pair and the individual factors: 5 N doubles) live in LDS when they fit: every phase
     // boundary is then an LDS round trip instead of one through L2.
     const size_t vec_bytes = (size_t)5 * 2 * a.n * sizeof(double);
     a.vec_lds = vec_bytes <= 144 * 1024;
