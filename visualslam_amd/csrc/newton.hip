@@ -12,9 +12,9 @@
 // back to the caller, which takes the eigenvalue route for it.
 //
 // The posterior square-root covariance (src/gaussian.hpp:513-516: S = triu(qr(diag(v^-1/2) Q^T)),
-// i.e. S^T S = H^-1) is formed as the R factor of U^-T:  U^-1 U^-T = H^-1.  It equals the
-// reference's S up to the signs of its rows, which there depend on the eigensolver's choice of
-// eigenvector signs.
+// i.e. the upper-triangular S with S^T S = H^-1) is formed as the inverse of the upper-triangular M
+// with M M^T = H (a Cholesky factorisation of the index-reversed H).  It equals the reference's S up
+// to the signs of its rows, which there depend on the eigensolver's choice of eigenvector signs.
 #include "linalg.hpp"
 
 #include <cmath>
@@ -177,32 +177,25 @@ __global__ void axpby_kernel(double a, const double *x, double b, const double *
     if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
 }
 
-__global__ __launch_bounds__(256) void transpose_kernel(const double *A, int n, double *B)
+// B(i, j) = A(n-1-i, n-1-j), or with `transposed` B(i, j) = A(n-1-j, n-1-i): both index reversals of a square matrix.
+__global__ __launch_bounds__(256) void reverse_kernel(const double *A, int n, double *B, int transposed)
 {
-    __shared__ double tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int j = ty; j < 32; j += 8) {
-        const int r = bx + tx, c = by + j;
-        tile[j][tx] = (r < n && c < n) ? A[(size_t)c * n + r] : 0.0;
-    }
-    __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int r = by + tx, c = bx + j;                    // B(r, c) = A(c, r)
-        if (r < n && c < n) B[(size_t)c * n + r] = tile[tx][j];
-    }
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= n) return;
+    const int ri = n - 1 - i, rj = n - 1 - j;
+    B[(size_t)j * n + i] = transposed ? A[(size_t)ri * n + rj] : A[(size_t)rj * n + ri];
 }
 
 size_t newton_ws_bytes(int n)
 {
     const size_t nn = (size_t)n * n;
-    return 2 * Arena::pad(nn * 8) + 8 * Arena::pad((size_t)n * 8) + Arena::pad(64) + Arena::pad(64) + qr_ws_bytes(n, n, 1);
+    return 2 * Arena::pad(nn * 8) + 8 * Arena::pad((size_t)n * 8) + Arena::pad(64) + Arena::pad(64);
 }
 
 namespace {
 struct NewtonDevice {
     double *U, *Hcur, *gcur, *xcur, *p, *t, *q, *xn, *Hp, *spare, *dots;
     int *info;
-    void *qws;
 };
 void newton_carve(void *ws, int n, NewtonDevice *w)
 {
@@ -213,7 +206,6 @@ void newton_carve(void *ws, int n, NewtonDevice *w)
     w->q = ar.take<double>(n); w->xn = ar.take<double>(n); w->Hp = ar.take<double>(n); w->spare = ar.take<double>(n);
     w->dots = ar.take<double>(8);
     w->info = ar.take<int>(16);
-    w->qws = ar.take<char>(qr_ws_bytes(n, n, 1));
 }
 }  // namespace
 
@@ -314,13 +306,15 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         else if (rho > 0.75 && pn > 0.8 * Delta) Delta = 2.0 * Delta;
         if (rho >= 0.001) { f = fn; VSLAM_TRY(accept()); }
     }
-    // ---- posterior: S = R factor of U^-T with U^T U = H at the final iterate ----
-    VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
-    VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
-    VSLAM_TRY(trtri_upper_dev(ctx, w.U, n, n, c->Hl, n, c->tws));        // Hl, W: scratch from here on
-    hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, c->Hl, n, c->W);
+    // ---- posterior: the upper-triangular S with S^T S = H^-1 at the final iterate.  With J the index reversal,
+    // J H J = U'^T U' (Cholesky) gives H = M M^T for the upper-triangular M = J U'^T J, hence S = M^-1
+    // (S^T S = M^-T M^-1 = H^-1): one factorisation and one triangular inverse, no QR. ----
+    hipLaunchKernelGGL(reverse_kernel, dim3(nb, n), dim3(256), 0, s, w.Hcur, n, w.U, 0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_TRY(qr_upper_dev(ctx, c->W, n, n, n, 0, 1, w.qws));
+    VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+    hipLaunchKernelGGL(reverse_kernel, dim3(nb, n), dim3(256), 0, s, w.U, n, c->Hl, 1);           // Hl, W: scratch from here on
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(trtri_upper_dev(ctx, c->Hl, n, n, c->W, n, c->tws));
     VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
     VSLAM_TRY(d2h(ctx, mu_post, w.xcur, (size_t)n * 8));
     VSLAM_TRY(d2h_2d(ctx, S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n));
