@@ -5,9 +5,13 @@ out; the former only checked output dimensions): parity with the reference is UN
 restatement is checked against what the cited code must satisfy: the analytic process Jacobian equals
 finite differences of f, the propagated RK4 Jacobian equals finite differences of the RK4 map, the
 factor reproduces the propagated covariance, and the dimensions of test/src/kalman.cpp's case."""
+import json
+import os
+
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
 from oracle import pyoracle as orc
 
 PT = np.diag([0.5, 0.5, 0.175])        # scenario 2, src/SLAM.cpp:99-106
@@ -112,3 +116,31 @@ def test_match_hamming_against_numpy():
     assert idx[3] == 200 and dist[3] == 0
     idx, dist = orc.match_hamming(q, np.zeros((0, 32), np.uint8))
     assert np.all(idx == -1)
+
+
+def _golden_cases():
+    with open(os.path.join(GOLDEN, "time_update.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def test_rk4_and_jacobian_against_mpmath_golden():
+    """tests/golden/time_update.json: the RK4 step and its Jacobian from an independent 50-digit mpmath
+    evaluation of the cited formulas (tests/golden/make_golden_time_update.py)."""
+    for case in _golden_cases():
+        n, dt = case["n"], case["dt"]
+        xn, J = orc.rk4_sde(np.array(case["xdw"]), PT, OT, dt)
+        want_x = np.array(case["xnext"])
+        want_J = np.array(case["J_colmajor"]).reshape(2 * n, n).T
+        assert np.abs(xn - want_x).max() <= 1e-14 * max(1.0, np.abs(want_x).max())
+        assert np.abs(J - want_J).max() <= 1e-13
+
+
+def test_time_update_covariance_against_mpmath_golden():
+    case = [c for c in _golden_cases() if "P_next_colmajor" in c][0]
+    n, dt = case["n"], case["dt"]
+    S = np.array(case["S_colmajor"]).reshape(n, n).T
+    mu = np.array(case["xdw"][:n])
+    mup, Sp = orc.time_update(mu, S, np.diag(case["pos_tune_diag"]), np.diag(case["ori_tune_diag"]), dt)
+    P = np.array(case["P_next_colmajor"]).reshape(n, n).T
+    assert np.abs(Sp.T @ Sp - P).max() <= 1e-13 * np.abs(P).max()
+    assert np.abs(mup - np.array(case["xnext"])).max() <= 1e-14

@@ -80,6 +80,29 @@ def test_errors(ctx):
         api.time_update(ctx, np.zeros(15), np.eye(15), PT, OT, -1.0)
 
 
+def test_covariance_against_mpmath_golden(ctx):
+    """tests/golden/time_update.json (50-digit mpmath evaluation of the cited formulas): propagated mean and
+    covariance of a 15-state filter, through the host-pointer entry (structured path: S is upper triangular)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from visualslam_amd import api
+    with open(os.path.join(GOLDEN, "time_update.json")) as fh:
+        case = [c for c in json.load(fh)["cases"] if "P_next_colmajor" in c][0]
+    n, dt = case["n"], case["dt"]
+    S = np.array(case["S_colmajor"]).reshape(n, n).T
+    mu = np.array(case["xdw"][:n])
+    mup, Sp = api.time_update(ctx, mu, S, np.diag(case["pos_tune_diag"]), np.diag(case["ori_tune_diag"]), dt)
+    P = np.array(case["P_next_colmajor"]).reshape(n, n).T
+    assert rel_err(Sp.T @ Sp, P) <= 1e-12
+    assert np.abs(mup - np.array(case["xnext"])).max() <= 1e-13
+    # a general (non-triangular) factor of the same covariance takes the dense path and gives the same covariance
+    rng = np.random.default_rng(1)
+    Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    mup2, Sp2 = api.time_update(ctx, mu, Qr @ S, np.diag(case["pos_tune_diag"]), np.diag(case["ori_tune_diag"]), dt)
+    assert rel_err(Sp2.T @ Sp2, P) <= 1e-12
+
+
 def test_structured_and_dense_paths_agree(ctx):
     """The same upper-triangular factors through both device paths (s_is_upper on / off), out of place."""
     import torch
