@@ -244,6 +244,14 @@ vslam_status vslam_time_update_batch_dev(vslam_ctx *ctx, const double *mu, const
  * re-triangularised by Householder QR and its leading (n-3) x (n-3) block returned. */
 vslam_status vslam_remove_landmark(vslam_ctx *ctx, const double *mu, const double *S, int n, int ldS, int j,
                                    double *mu_out, double *S_out, int ldSout);
+/* The same on device-resident state (src/SLAM.cpp:796-820): mu (n), S (n x n, ldS), mu_out (n-3) and
+ * S_out ((n-3) x (n-3), ldSout) are device pointers; the outputs must not overlap the inputs.
+ * s_is_upper != 0: the caller guarantees an upper-triangular S (every factor this library or the
+ * reference's QR returns); its strict lower part is then not read and the reflectors, which only span
+ * four rows each, are applied in O(n^2) work.  0: dense QR.  Queued on the context's stream, not
+ * synchronised (vslam_remove_landmark checks the triangularity itself). */
+vslam_status vslam_remove_landmark_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int ldS, int j,
+                                       double *mu_out, double *S_out, int ldSout, int s_is_upper);
 
 /* ---- descriptor matching ----
  * cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches), src/SLAM.cpp:222,355: for each of the

@@ -51,6 +51,63 @@ def test_remove_landmark_dense_factor_signs(ctx, n, j):
     assert rel_err(S1, S0) < 1e-9
 
 
+@pytest.mark.parametrize("n,j", [(162, 20), (462, 0), (462, 149), (1212, 3)])
+def test_remove_landmark_structured_and_dense_paths_agree(ctx, n, j, monkeypatch):
+    """Upper-triangular factors take the structured kernels (reflectors over four rows); VSLAM_REMOVE_DENSE=1
+    forces the dense QR on the same input.  n = 1212 runs the launch-per-panel form."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(7 * n + j)
+    mu = rng.standard_normal(n)
+    S = np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)
+    mu1, S1 = api.remove_landmark(ctx, mu, S, j)
+    monkeypatch.setenv("VSLAM_REMOVE_DENSE", "1")
+    mu2, S2 = api.remove_landmark(ctx, mu, S, j)
+    monkeypatch.delenv("VSLAM_REMOVE_DENSE")
+    assert np.array_equal(mu1, mu2)
+    assert rel_err(S1, S2) < 1e-11
+    assert not np.tril(S1, -1).any()
+    if n <= 462:
+        assert rel_err(S1, orc.remove_landmark(mu, S, j)[1]) < 1e-9
+
+
+@pytest.mark.parametrize("upper", [True, False])
+def test_remove_landmark_dev_matches_host_entry(ctx, upper):
+    """Device-resident form: same result as the host-pointer entry on both routes."""
+    import torch
+    from visualslam_amd import api
+    n, j = 162, 31
+    rng = np.random.default_rng(11)
+    mu = rng.standard_normal(n)
+    S = np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)
+    mu0, S0 = api.remove_landmark(ctx, mu, S, j)
+    dev = torch.device("cuda:0")
+    dmu = torch.tensor(mu, device=dev)
+    dS = torch.tensor(np.ascontiguousarray(S.T), device=dev)            # column-major S
+    dmo = torch.empty(n - 3, dtype=torch.float64, device=dev)
+    dSo = torch.full((n - 3, n - 3), float("nan"), dtype=torch.float64, device=dev)
+    api.remove_landmark_dev(ctx, dmu, dS, j, dmo, dSo, s_is_upper=upper)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(dmo.cpu().numpy(), mu0)
+    assert rel_err(dSo.cpu().numpy().T, S0) < 1e-11
+
+
+def test_remove_landmark_general_square_factor(ctx):
+    """A factor that is not upper triangular goes through the dense QR; the marginal covariance is what counts."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    n, j = 45, 6
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((n, n))
+    mu = rng.standard_normal(n)
+    mu0, S0 = orc.remove_landmark(mu, S, j)
+    mu1, S1 = api.remove_landmark(ctx, mu, S, j)
+    assert rel_err(S1, S0) < 1e-9
+    keep = [i for i in range(n) if not 12 + 3 * j <= i < 15 + 3 * j]
+    assert rel_err(S1.T @ S1, (S.T @ S)[np.ix_(keep, keep)]) < 1e-12
+
+
 def test_remove_landmark_errors(ctx):
     from visualslam_amd import api
     with pytest.raises(api.VslamError):

@@ -347,6 +347,14 @@ def time_update_batch_dev(ctx, mu, S, n, pos_tune, ori_tune, dt, mu_out, S_out, 
                                              _tp(mu_out), _tp(S_out), int(bool(s_is_upper))), ctx.ptr)
 
 
+def remove_landmark_dev(ctx, mu, S, j, mu_out, S_out, s_is_upper=True):
+    """torch f64 tensors on the GPU: mu (n), S column-major n x n (i.e. the tensor holds S^T), mu_out (n-3),
+    S_out column-major (n-3) x (n-3); outputs must not overlap the inputs."""
+    n = mu.shape[0]
+    check(ctx._L.vslam_remove_landmark_dev(ctx.ptr, _tp(mu), _tp(S), n, n, int(j), _tp(mu_out), _tp(S_out), max(n - 3, 1),
+                                           int(bool(s_is_upper))), ctx.ptr)
+
+
 def match_hamming_batch_dev(ctx, query, train, idx, dist=None, nt_each=None):
     """torch u8 tensors on the GPU: query (B, nq, bytes), train (B, nt, bytes); idx/dist (B, nq) int32."""
     B, nq, nb = query.shape
