@@ -23,160 +23,43 @@ namespace vslam {
 
 
 // ---- host symmetric eigensolver (the reference's Eigen::SelfAdjointEigenSolver, src/fmin.hpp:42-44) ----
-// Householder tridiagonalisation, accumulation of the transformation (row-wise, so every inner loop
-// runs over contiguous memory) and implicit-shift QL.  The QL iteration itself only touches the two
+// Householder tridiagonalisation (the symmetric matrix-vector product of each step as one pass over
+// the contiguous rows of the lower triangle), accumulation of the transformation (row-wise, so every
+// inner loop runs over contiguous memory) and implicit-shift QL.  The QL iteration itself only touches the two
 // diagonals; its plane rotations are recorded and then applied to the vectors, which are kept
 // transposed (row i = vector i) so that a rotation runs over two contiguous rows.
 // (Tried on the 16 cores a GPU box gives one process: a lock-step thread team for the first two phases
 // loses to one thread because of the barrier per Householder step, and splitting only the rotation
 // pass by columns gains 15 %: not worth threads inside the library.)
 namespace {
-
 struct Rot { int i; double c, s; };
 
-// sqrt(a^2 + b^2); the library routine's protection against overflow and underflow is only paid for
-// when the plain formula leaves the normal range.
-inline double pythag(double a, double b)
-{
-    const double r2 = a * a + b * b;
-    if (r2 > 1e-290 && r2 < 1e290) return std::sqrt(r2);
-    return std::hypot(a, b);
-}
-
-void apply_rotations(const std::vector<Rot> &rots, double *zt, int ldz, int k0, int k1)
-{
-    const int w = k1 - k0;
-    for (const Rot &q : rots) {
-        const double c = q.c, s = q.s;
-        double *__restrict zi = zt + (size_t)q.i * ldz + k0;
-        double *__restrict zi1 = zi + ldz;
-        for (int k = 0; k < w; ++k) {
-            const double f1 = zi1[k], f0 = zi[k];
-            zi1[k] = s * f0 + c * f1;
-            zi[k] = c * f0 - s * f1;
-        }
-    }
-}
-
+// The solver is compiled twice from sym_eig.inc: for the baseline x86-64 instruction set and for AVX2 + FMA
+// (its loops are long contiguous axpy / dot / rotation passes over doubles); the variant is chosen once
+// from the CPU the process runs on.
+#define EIG_FN(name) name##_base
+#define EIG_ATTR
+#include "sym_eig.inc"
+#undef EIG_FN
+#undef EIG_ATTR
+#if defined(__x86_64__)
+#define EIG_FN(name) name##_avx2
+#define EIG_ATTR __attribute__((target("avx2,fma")))
+#include "sym_eig.inc"
+#undef EIG_FN
+#undef EIG_ATTR
+#endif
 }  // namespace
 
 // Eigen-decomposition of the symmetric matrix whose lower triangle is in H
 // (column-major, n x n).  Q column-major eigenvectors, v ascending eigenvalues.
 void sym_eig_host(const double *H, int n, double *Q, double *v)
 {
-    const int ldz = (n + 7) & ~7;                 // rows of the vector array start on cache lines: thread slices share none
-    std::vector<double> a((size_t)n * n), ztbuf((size_t)n * ldz + 8), e(n, 0.0), d(n, 0.0), gv(n, 0.0);
-    double *zt = ztbuf.data() + ((64 - (reinterpret_cast<uintptr_t>(ztbuf.data()) & 63)) & 63) / 8;
-    auto A = [&](int i, int j) -> double & { return a[(size_t)i * n + j]; };     // row-major working copy
-    for (int j = 0; j < n; ++j)
-        for (int i = j; i < n; ++i) { A(i, j) = H[(size_t)j * n + i]; A(j, i) = H[(size_t)j * n + i]; }
-    // --- Householder reduction to tridiagonal form ---
-    for (int i = n - 1; i >= 1; --i) {
-        const int l = i - 1;
-        double h = 0.0, scale = 0.0;
-        double *ri = &A(i, 0);
-        if (l > 0) {
-            for (int k = 0; k <= l; ++k) scale += std::fabs(ri[k]);
-            if (scale == 0.0) e[i] = ri[l];
-            else {
-                for (int k = 0; k <= l; ++k) { ri[k] /= scale; h += ri[k] * ri[k]; }
-                double f = ri[l];
-                double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
-                e[i] = scale * g;
-                h -= f * g;
-                ri[l] = f - g;
-                f = 0.0;
-                for (int j = 0; j <= l; ++j) {
-                    A(j, i) = ri[j] / h;
-                    g = 0.0;
-                    const double *rj = &A(j, 0);
-                    for (int k = 0; k <= j; ++k) g += rj[k] * ri[k];
-                    for (int k = j + 1; k <= l; ++k) g += A(k, j) * ri[k];
-                    e[j] = g / h;
-                    f += e[j] * ri[j];
-                }
-                const double hh = f / (h + h);
-                for (int j = 0; j <= l; ++j) {
-                    f = ri[j];
-                    e[j] = g = e[j] - hh * f;
-                    double *rj = &A(j, 0);
-                    for (int k = 0; k <= j; ++k) rj[k] -= f * e[k] + g * ri[k];
-                }
-            }
-        } else e[i] = ri[l];
-        d[i] = h;
-    }
-    // --- accumulation of the transformation, row-wise: g_j = sum_k A(i,k) A(k,j), then A(k,j) -= g_j A(k,i) ---
-    d[0] = 0.0; e[0] = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const int l = i - 1;
-        if (d[i] != 0.0) {
-            double *g = gv.data();
-            for (int j = 0; j <= l; ++j) g[j] = 0.0;
-            for (int k = 0; k <= l; ++k) {
-                const double aik = A(i, k);
-                const double *rk = &A(k, 0);
-                for (int j = 0; j <= l; ++j) g[j] += aik * rk[j];
-            }
-            for (int k = 0; k <= l; ++k) {
-                const double aki = A(k, i);
-                double *rk = &A(k, 0);
-                for (int j = 0; j <= l; ++j) rk[j] -= g[j] * aki;
-            }
-        }
-        d[i] = A(i, i);
-        A(i, i) = 1.0;
-        for (int j = 0; j <= l; ++j) A(j, i) = A(i, j) = 0.0;
-    }
-    for (int k = 0; k < n; ++k)
-        for (int i = 0; i < n; ++i) zt[(size_t)i * ldz + k] = A(k, i);
-    // --- implicit-shift QL on the tridiagonal matrix; rotations recorded in batches and applied by the team ---
-    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
-    e[n - 1] = 0.0;
-    const double eps = std::numeric_limits<double>::epsilon();
-    const size_t rot_cap = (size_t)1 << 21;
-    std::vector<Rot> rots;
-    rots.reserve(rot_cap + (size_t)n);
-    int l = 0, iter = 0;
-    while (l < n) {
-        rots.clear();
-        while (l < n && rots.size() < rot_cap) {
-            int m;
-            for (m = l; m < n - 1; ++m) {
-                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-                if (std::fabs(e[m]) <= eps * dd) break;
-            }
-            if (m == l || ++iter > 200) { ++l; iter = 0; continue; }
-            double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-            double r = pythag(g, 1.0);
-            g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
-            double s = 1.0, c = 1.0, p = 0.0;
-            int i;
-            for (i = m - 1; i >= l; --i) {
-                const double f = s * e[i], b = c * e[i];
-                e[i + 1] = r = pythag(f, g);
-                if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
-                s = f / r; c = g / r;
-                g = d[i + 1] - p;
-                r = (d[i] - g) * s + 2.0 * c * b;
-                d[i + 1] = g + (p = s * r);
-                g = c * r - b;
-                rots.push_back(Rot{i, c, s});
-            }
-            if (r == 0.0 && i >= l) continue;
-            d[l] -= p; e[l] = g; e[m] = 0.0;
-        }
-        if (rots.empty()) continue;
-        apply_rotations(rots, zt, ldz, 0, n);
-    }
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d[x] < d[y]; });
-    for (int c = 0; c < n; ++c) {
-        v[c] = d[order[c]];
-        const double *src = zt + (size_t)order[c] * ldz;
-        for (int k = 0; k < n; ++k) Q[(size_t)c * n + k] = src[k];
-    }
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (wide) { sym_eig_avx2(H, n, Q, v); return; }
+#endif
+    sym_eig_base(H, n, Q, v);
 }
 
 static double norm2(const std::vector<double> &a) { double s = 0; for (double t : a) s += t * t; return std::sqrt(s); }
