@@ -89,6 +89,24 @@ def cpu_baseline(x, y, vis, budget_s=12.0):
     }
 
 
+def host_info():
+    """CPU model and core counts of the node the CPU baselines were timed on."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = None
+    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cores": usable}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +228,7 @@ def main():
             "results_gathered_to_root": gathered_ok,
             "single_instance_latency_us": single_us,
             "single_instance_updates_per_s": L / (single_us * 1e-6),
+            "host": host_info(),
         }
         if corner is not None:
             out["corner"] = corner

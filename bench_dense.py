@@ -103,9 +103,13 @@ def run_dense_leg(ctx, dev, stream):
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-    from run_iekf_bank import bank_throughput
+    from run_iekf_bank import bank_throughput, batched_throughput
     rate8, _ = bank_throughput(150, 8, 4, api.TRS_CHOLESKY, dev.index or 0)
     upd["bank_8_contexts_updates_per_s"] = rate8
+    rate512, dt512, nfail, _ = batched_throughput(150, 512, dev.index or 0, reps=1)
+    upd["bank_512_lock_step_updates_per_s"] = rate512
+    upd["bank_512_lock_step_ms"] = dt512 * 1e3
+    upd["bank_512_not_positive_definite"] = nfail
     return {
         "frame_steps_150_landmarks": frame,
         "qr": {"workload": "in-place Householder QR (R only), %d x %d fp64, device resident" % (n, n), "ms": ms,

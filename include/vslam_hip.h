@@ -174,6 +174,20 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
                                            double *mu_post, double *S_post, int ldSp,
                                            int32_t *fmin_code, int32_t *iters, int32_t *cost_evals);
 
+/* The same update (src/gaussian.hpp:469-532 as called at src/SLAM.cpp:492) for a bank of `batch`
+ * independent filters held on the device: mu (batch x n), S (batch matrices n x n, column-major,
+ * ld n, upper triangular), y (batch x 2L), visible (batch x L), mu_post and S_post like mu and S are
+ * device pointers; fmin_code / iters / status are host arrays of `batch` entries (each may be NULL).
+ * Every step of the trust-region iteration runs over the whole bank in one set of kernel launches,
+ * on the Cholesky route described below (the reference's sequence of iterates per filter).
+ * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = its Hessian was not positive definite
+ * at some iterate: its outputs are meaningless and the caller redoes that filter with
+ * vslam_measurement_update_iekf.  Returns after the results are complete. */
+vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu,
+                                                     const double *S, int n, int batch, const double *y,
+                                                     const uint8_t *visible, double sigma, double *mu_post,
+                                                     double *S_post, int32_t *fmin_code, int32_t *iters, int32_t *status);
+
 /* How vslam_measurement_update_iekf solves the trust-region subproblem of src/fmin.cpp:40-131.
  * EIG (default): as the reference, from a symmetric eigendecomposition of the Hessian taken on
  *      the host at every accepted iterate (O(n^3) scalar work per iterate).

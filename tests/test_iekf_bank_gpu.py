@@ -1,0 +1,91 @@
+"""Bank of filters through vslam_measurement_update_iekf_batch_dev against the single-filter entry
+(Cholesky route) on the same inputs: posterior mean and covariance to 1e-9, same fmin code."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bank(L, B, seed0, perturb=True):
+    from visualslam_amd import synthetic as syn
+    scs = [syn.Scene(L, seed0 + i, dense_S=True) for i in range(B)]
+    rng = np.random.default_rng(seed0)
+    mus = []
+    for sc in scs:
+        d = np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)])
+        mus.append(sc.x + (d if perturb else 0.0))
+    return scs, np.stack(mus)
+
+
+@pytest.mark.parametrize("L,B", [(5, 3), (50, 6), (150, 4)])
+def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
+    import torch
+    from visualslam_amd import api
+    scs, mus = _bank(L, B, 700 + L)
+    n = 12 + 3 * L
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    y = torch.tensor(np.stack([sc.y for sc in scs]), device=dev)
+    vis = torch.tensor(np.stack([sc.visible for sc in scs]).astype(np.uint8), device=dev)
+    mup = torch.empty_like(mu)
+    Sp = torch.empty_like(S)
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, scs[0].sigma, mup, Sp)
+    torch.cuda.synchronize()
+    assert status.sum() < B
+    ctx.set_trs_solver(api.TRS_CHOLESKY)
+    try:
+        for b, sc in enumerate(scs):
+            c0, m0, S0, it0, _ = api.measurement_update_iekf(ctx, gcam, mus[b], sc.S, sc.y, sc.visible, sc.sigma)
+            if status[b]:                      # not positive definite somewhere: the single-filter entry falls back too
+                assert ctx.last_trs_route() == api.TRS_EIG
+                continue
+            assert ctx.last_trs_route() == api.TRS_CHOLESKY
+            m1 = mup[b].cpu().numpy()
+            S1 = Sp[b].cpu().numpy().T
+            assert code[b] == c0
+            assert abs(int(iters[b]) - it0) <= 1
+            assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+            assert not np.tril(S1, -1).any()
+    finally:
+        ctx.set_trs_solver(api.TRS_EIG)
+
+
+def test_bank_rejects_bad_arguments(ctx, gcam):
+    import torch
+    from visualslam_amd import api
+    dev = torch.device("cuda:0")
+    mu = torch.zeros((2, 16), dtype=torch.float64, device=dev)          # 16 is not 12 + 3L
+    S = torch.zeros((2, 16, 16), dtype=torch.float64, device=dev)
+    y = torch.zeros((2, 2), dtype=torch.float64, device=dev)
+    vis = torch.ones((2, 1), dtype=torch.uint8, device=dev)
+    with pytest.raises(api.VslamError):
+        api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, 7.0, mu.clone(), S.clone())
+    mu = torch.zeros((2, 15), dtype=torch.float64, device=dev)
+    S = torch.eye(15, dtype=torch.float64, device=dev).repeat(2, 1, 1)
+    with pytest.raises(api.VslamError):
+        api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, 0.0, mu.clone(), S.clone())
+
+
+def test_bank_of_one_and_repeat_call(ctx, gcam):
+    """A bank of one filter, called twice on the same context (workspace reuse), gives the same answer twice."""
+    import torch
+    from visualslam_amd import api
+    scs, mus = _bank(50, 1, 31)
+    sc = scs[0]
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.ascontiguousarray(sc.S.T)[None], device=dev)
+    y = torch.tensor(sc.y[None], device=dev)
+    vis = torch.tensor(sc.visible.astype(np.uint8)[None], device=dev)
+    outs = []
+    for _ in range(2):
+        mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+        code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, sc.sigma, mup, Sp)
+        torch.cuda.synchronize()
+        outs.append((code.copy(), status.copy(), mup.cpu().numpy(), Sp.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])

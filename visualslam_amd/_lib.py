@@ -100,6 +100,7 @@ def _declare(L):
         "vslam_iekf_post_sqrt": [_vp, _vp, _vp, _i, _vp],
         "vslam_condition_on_marginal": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i],
         "vslam_cost_joint_density": [_vp, C.POINTER(Camera), _vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _vp],
+        "vslam_measurement_update_iekf_batch_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp, _vp],
         "vslam_measurement_update_iekf": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _vp, _d,
                                           _vp, _vp, _i, _vp, _vp, _vp],
         "vslam_individual_compat": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp],

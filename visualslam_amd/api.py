@@ -247,6 +247,20 @@ def measurement_update_iekf(ctx, cam, mu, S, y, visible, sigma):
     return int(info[0]), mup, Sp, int(info[1]), int(info[2])
 
 
+def measurement_update_iekf_batch_dev(ctx, cam, mu, S, y, visible, sigma, mu_post, S_post):
+    """Bank of filters on the GPU (torch tensors): mu (B, n) f64, S (B, n, n) holding each column-major
+    factor, y (B, 2L) f64, visible (B, L) u8; mu_post / S_post alike.  Returns (fmin_code, iters, status)
+    int32 arrays of B entries; status 1 marks a filter to redo with measurement_update_iekf."""
+    B, n = mu.shape
+    code = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    check(ctx._L.vslam_measurement_update_iekf_batch_dev(ctx.ptr, C.byref(cam), _tp(mu), _tp(S), n, B, _tp(y), _tp(visible),
+                                                         float(sigma), _tp(mu_post), _tp(S_post), _p(code), _p(iters),
+                                                         _p(status)), ctx.ptr)
+    return code, iters, status
+
+
 def normcdf(z):
     return float(_lib.lib().vslam_normcdf(float(z)))
 

@@ -7,11 +7,6 @@
 
 namespace vslam {
 
-vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int n,
-                                 const double *x, size_t sx, const double *y, size_t sy,
-                                 const uint8_t *vis, size_t sv, double sigma,
-                                 double *value, double *g, size_t sg, double *H, int ldH, size_t sH, int32_t *code);
-
 __global__ void vec_sub_kernel(const double *a, const double *b, double *out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,7 +355,7 @@ vslam_status cost_eval_dev(vslam_ctx *ctx, const CamK &k, double sigma, CostDevi
     hipStream_t s = ctx->stream;
     VSLAM_TRY(log_gaussian_dev(ctx, c->x, c->mu, c->S, n, n, c->vals + 0, c->gp, c->prior_ready ? nullptr : c->Hp, c->tmp, c->W, c->tws));
     c->prior_ready = true;
-    VSLAM_TRY(launch_point_loglik(ctx, k, 1, n, c->x, 0, c->y, 0, c->vis, 0, sigma, c->vals + 1, c->gl, 0, c->Hl, n, 0, nullptr));
+    VSLAM_TRY(launch_point_loglik(ctx, k, 1, n, c->x, 0, c->y, 0, c->vis, 0, sigma, c->vals + 1, c->gl, 0, c->Hl, n, 0, nullptr, nullptr));
     hipLaunchKernelGGL(neg_sum_scalar_kernel, dim3(1), dim3(1), 0, s, c->vals + 0, c->vals + 1, c->vals + 2);
     hipLaunchKernelGGL(neg_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c->gp, c->gl, c->g, (size_t)n);
     const size_t nn = (size_t)n * n;

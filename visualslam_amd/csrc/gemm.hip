@@ -30,6 +30,7 @@ struct GemmArgs {
     const double *A, *B;
     double *C;
     size_t sA, sB, sC, sSplit;
+    const int *active;
 };
 
 template <bool TA>
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.c_upper && m0 > n0 + BN - 1) return;             // tile entirely below the diagonal of C: not wanted
     const int split = blockIdx.y, b = blockIdx.z;
+    if (g.active && !g.active[b]) return;
     const double *A = g.A + (size_t)b * g.sA;
     const double *B = g.B + (size_t)b * g.sB;
     double *C = g.C + (size_t)b * g.sC + (size_t)split * g.sSplit;
@@ -170,7 +172,7 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream)
     a.M = d.M; a.N = d.N; a.K = d.K; a.lda = d.lda; a.ldb = d.ldb; a.ldc = d.ldc;
     a.amode = (int)d.amode; a.b_upper = d.b_upper ? 1 : 0; a.c_upper = d.c_upper ? 1 : 0;
     a.alpha = d.alpha; a.beta = d.beta; a.A = d.A; a.B = d.B; a.C = d.C;
-    a.sA = d.strideA; a.sB = d.strideB; a.sC = d.strideC; a.sSplit = d.strideSplit;
+    a.sA = d.strideA; a.sB = d.strideB; a.sC = d.strideC; a.sSplit = d.strideSplit; a.active = d.active;
     int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
     kchunk = ((kchunk + BK - 1) / BK) * BK;
     a.kchunk = kchunk > 0 ? kchunk : BK;

@@ -53,6 +53,7 @@ struct GemmDesc {
     const double *B; int ldb; size_t strideB = 0;
     double *C; int ldc; size_t strideC = 0;
     int batch = 1;
+    const int *active = nullptr;   // device, optional: batch members whose entry is 0 are skipped
     int ksplit = 1;          // >1: split K; slab s of batch b is written (beta ignored) at
     size_t strideSplit = 0;  //     C + b*strideC + s*strideSplit
 };
@@ -71,9 +72,20 @@ vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda
 // W = inverse of the upper-triangular S (n x n); strict lower part of W zeroed.
 size_t trtri_ws_bytes(int n);
 vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws);
+size_t trtri_batch_ws_bytes(int n, int batch);
+vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
+                                   int batch, void *ws);
 
 // Solves S^T z = b (trans = true) or S z = b (trans = false) for one vector, S upper triangular.
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z);
+
+// Batched point-landmark log-likelihood (point_loglik.hip), all pointers device, strides in elements;
+// active (optional, device): instances whose entry is 0 are skipped.
+vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int n,
+                                 const double *x, size_t sx, const double *y, size_t sy,
+                                 const uint8_t *vis, size_t sv, double sigma,
+                                 double *value, double *g, size_t sg, double *H, int ldH, size_t sH, int32_t *code,
+                                 const int *active);
 
 // Device buffers of one CostJointDensity problem (reference src/gaussian.hpp:435-467),
 // carved out of the context workspace; shared by the cost entry point and the
@@ -96,6 +108,7 @@ vslam_status cost_eval_dev(vslam_ctx *ctx, const CamK &k, double sigma, CostDevi
 // (outputs are then meaningless and the caller takes the eigenvalue route).
 size_t newton_ws_bytes(int n);
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
+vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active);
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
                                 int *status_out);

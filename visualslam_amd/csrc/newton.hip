@@ -32,10 +32,13 @@ constexpr int CB = 64;           // Cholesky block
 // one wins); the arithmetic carries on with NaNs.
 constexpr int PLD = CB + 2;      // even: the eight broadcast values of a row are two aligned 16-byte pairs apart
 constexpr int PR = 8;
-__global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info)
+__global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info, size_t strideA, const int *active)
 {
     __shared__ __align__(16) double U[CB * PLD];                  // U[l][j] at l * PLD + j
     const int lane = threadIdx.x;
+    if (active && !active[blockIdx.y]) return;                    // instance blockIdx.y of a batch (stride strideA, one info word each)
+    A += (size_t)blockIdx.y * strideA;
+    info += blockIdx.y;
     for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
         double v[16];
 #pragma unroll
@@ -80,10 +83,12 @@ __global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int
 // columns; lane = column with its 64 entries in registers, forward substitution
 // x_k = (b_k - sum_{l<k} U[l][k] x_l) / U[k][k] with U read from LDS (the same address in every lane).
 constexpr int CLD = CB + 2;
-__global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int n, int j0)
+__global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active)
 {
     __shared__ __align__(16) double Ut[CB * CLD];                 // Ut[k][l] = U[l][k]: column k contiguous in l
     const int lane = threadIdx.x;
+    if (active && !active[blockIdx.y]) return;
+    A += (size_t)blockIdx.y * strideA;
     const int c0 = j0 + CB + blockIdx.x * CB, nc = min(CB, n - c0);
     for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
         double u[16];
@@ -116,34 +121,49 @@ __global__ void add_diag_kernel(double *A, int lda, int n, double lam)
     if (i < n) A[(size_t)i * lda + i] += lam;
 }
 
-__global__ void zero_below_diag_kernel(double *A, int lda, int n)
+// strict lower triangle := 0 for matrix blockIdx.y of a batch (grid-stride over the n*n elements)
+__global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA, const int *active)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (r < n && r > c) A[(size_t)c * lda + r] = 0.0;
+    if (active && !active[blockIdx.y]) return;
+    double *Ab = A + (size_t)blockIdx.y * strideA;
+    const size_t nn = (size_t)n * n, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nn; idx += stride) {
+        const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
+        if (r > c) Ab[(size_t)c * lda + r] = 0.0;
+    }
 }
 
-// In-place upper Cholesky A = U^T U of the symmetric n x n matrix in A (both triangles are
-// overwritten: U above, zeros below).  *info (device) must be 0 on entry.
-vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info)
+// In-place upper Cholesky A = U^T U of `batch` symmetric n x n matrices (element stride strideA; both
+// triangles are overwritten: U above, zeros below).  info: one device word per matrix, 0 on entry.
+// active (device, may be null): matrices whose entry is 0 are left alone (except for the zeroing of
+// their strict lower triangle).
+vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active)
 {
     hipStream_t s = ctx->stream;
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
-        hipLaunchKernelGGL(potf2_upper_kernel, dim3(1), dim3(64), 0, s, A, lda, j0, jb, info);
+        hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(64), 0, s, A, lda, j0, jb, info, strideA, active);
         const int rest = n - j0 - jb;
         if (rest <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB), dim3(64), 0, s, A, lda, n, j0);
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB, batch), dim3(64), 0, s, A, lda, n, j0, strideA, active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         GemmDesc g;                                   // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
         g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0; g.c_upper = true;
-        g.A = A + (size_t)(j0 + jb) * lda + j0; g.lda = lda;
-        g.B = g.A; g.ldb = lda;
-        g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda;
+        g.A = A + (size_t)(j0 + jb) * lda + j0; g.lda = lda; g.strideA = strideA;
+        g.B = g.A; g.ldb = lda; g.strideB = strideA;
+        g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda; g.strideC = strideA;
+        g.batch = batch; g.active = active;
         VSLAM_TRY(gemm_f64(ctx, g));
     }
-    hipLaunchKernelGGL(zero_below_diag_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, A, lda, n);
+    const size_t zblocks = ((size_t)n * n + 4095) / 4096;
+    hipLaunchKernelGGL(zero_below_diag_kernel, dim3((unsigned)(zblocks < 1024 ? zblocks : 1024), batch), dim3(256), 0, s, A, lda, n, strideA, active);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
+}
+
+vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info)
+{
+    return potrf_upper_batch_dev(ctx, A, n, lda, 0, 1, info, nullptr);
 }
 
 // out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.

@@ -38,6 +38,7 @@ struct LoglikArgs {
     int32_t *code;
     int ldH, n, L, P;
     double is2, lconst;
+    const int *active;       // optional: batch instances whose entry is 0 are skipped
 };
 
 constexpr int kThreads = 256;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(kThreads) void point_loglik_kernel(CamK cam, Loglik
 {
     extern __shared__ double vals[];                   // [P][3 columns][9 rows] parked non-zeros of a landmark panel
     const int b = blockIdx.y, tid = threadIdx.x;
+    if (a.active && !a.active[b]) return;
     const double *x = a.x + (size_t)b * a.sx;
     const double *y = a.y + (size_t)b * a.sy;
     const uint8_t *vis = a.vis + (size_t)b * a.sv;
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(kThreads) void loglik_terms_kernel(CamK cam, TermsA
 {
     const LoglikArgs &a = t.a;
     const int b = blockIdx.y, tid = threadIdx.x, L = a.L;
+    if (a.active && !a.active[b]) return;
     const double *x = a.x + (size_t)b * a.sx;
     const double *y = a.y + (size_t)b * a.sy;
     const uint8_t *vis = a.vis + (size_t)b * a.sv;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
     extern __shared__ double srec[];                   // records of the landmarks whose columns this slice touches
     const LoglikArgs &a = t.a;
     const int b = blockIdx.y, tid = threadIdx.x, n = a.n, L = a.L;
+    if (a.active && !a.active[b]) return;
     double *H = a.H + (size_t)b * a.sH;
     const double *rec = t.rec + (size_t)b * kRecFields * L;
     const double *part_b = t.part + (size_t)b * t.nblk * 28;
@@ -386,7 +390,7 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
                                  const double *x, size_t sx, const double *y, size_t sy,
                                  const uint8_t *vis, size_t sv, double sigma,
                                  double *value, double *g, size_t sg, double *H, int ldH, size_t sH,
-                                 int32_t *code)
+                                 int32_t *code, const int *active)
 {
     if (!x || !y || !vis || !value) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null input/value pointer");
     if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L with L>=1", n);
@@ -396,7 +400,7 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
     if (!(sigma > 0.0)) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: sigma must be positive");
     LoglikArgs a;
     a.x = x; a.sx = sx; a.y = y; a.sy = sy; a.vis = vis; a.sv = sv;
-    a.value = value; a.g = g; a.sg = sg; a.H = H; a.sH = sH; a.code = code;
+    a.value = value; a.g = g; a.sg = sg; a.H = H; a.sH = sH; a.code = code; a.active = active;
     a.ldH = ldH; a.n = n; a.L = (n - 12) / 3;
     a.P = pick_panel(a.L, batch);
     a.is2 = 1.0 / (sigma * sigma);
@@ -444,7 +448,7 @@ extern "C" vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_point_loglik(ctx, k, batch, n, x, stride_x, y, stride_y, visible, stride_vis, sigma, value, g,
-                               stride_g, H, ldH, stride_H, code);
+                               stride_g, H, ldH, stride_H, code, nullptr);
 }
 
 extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
@@ -472,7 +476,7 @@ extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *c
     VSLAM_TRY(h2d(ctx, dx, x, n * 8));
     VSLAM_TRY(h2d(ctx, dy, y, 2 * L * 8));
     VSLAM_TRY(h2d(ctx, dv, visible, L));
-    VSLAM_TRY(launch_point_loglik(ctx, k, 1, n, dx, 0, dy, 0, dv, 0, sigma, dval, g ? dg : (H ? dg : nullptr), 0, dH, n, 0, dc));
+    VSLAM_TRY(launch_point_loglik(ctx, k, 1, n, dx, 0, dy, 0, dv, 0, sigma, dval, g ? dg : (H ? dg : nullptr), 0, dH, n, 0, dc, nullptr));
     VSLAM_TRY(d2h(ctx, value, dval, 8));
     if (g) VSLAM_TRY(d2h(ctx, g, dg, n * 8));
     if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));

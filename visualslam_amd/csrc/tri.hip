@@ -17,8 +17,10 @@ constexpr int TBK = 64;          // diagonal block of the triangular inverse
 // smaller) of S; D[b] (ld TBK, zeros below the diagonal) receives the inverse.  Lane c owns column
 // c of the inverse and back-substitutes e_c:  x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r];
 // both matrices live in LDS (U read as broadcasts, the inverse lane-contiguous).
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *Dall)
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *Dall, size_t strideS, size_t strideD)
 {
+    S += (size_t)blockIdx.y * strideS;                 // instance blockIdx.y of a batch
+    Dall += (size_t)blockIdx.y * strideD;
     extern __shared__ double trtri_lds[];
     double *U = trtri_lds;                        // [TBK][TBK + 1]
     double *X = trtri_lds + TBK * (TBK + 1);      // [TBK][TBK], X[r][c]
@@ -45,47 +47,62 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS
     for (int r = 0; r < TBK; ++r) D[(size_t)c * TBK + r] = (c < jb && r <= c) ? X[r * TBK + c] : 0.0;
 }
 
-__global__ void copy_block_kernel(const double *src, int lds, double *dst, int ldd, int rows, int cols, double scale)
+__global__ void copy_block_kernel(const double *src, int lds, double *dst, int ldd, int rows, int cols, double scale, size_t stride_src,
+                                  size_t stride_dst)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (r < rows && c < cols) dst[(size_t)c * ldd + r] = scale * src[(size_t)c * lds + r];
+    if (r < rows && c < cols) dst[(size_t)blockIdx.z * stride_dst + (size_t)c * ldd + r] = scale * src[(size_t)blockIdx.z * stride_src + (size_t)c * lds + r];
 }
 
-__global__ void zero_lower_block_kernel(double *W, int ldW, int n)
+__global__ void zero_lower_block_kernel(double *W, int ldW, int n, size_t strideW)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (r < n && r > c) W[(size_t)c * ldW + r] = 0.0;
+    if (r < n && r > c) W[(size_t)blockIdx.z * strideW + (size_t)c * ldW + r] = 0.0;
 }
 
 size_t trtri_ws_bytes(int n) { return Arena::pad((size_t)((n + TBK - 1) / TBK) * TBK * TBK * 8) + Arena::pad((size_t)n * TBK * 8); }
+size_t trtri_batch_ws_bytes(int n, int batch)
+{
+    return Arena::pad((size_t)batch * ((n + TBK - 1) / TBK) * TBK * TBK * 8) + Arena::pad((size_t)batch * n * TBK * 8);
+}
 
-vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws)
+// W = S^-1 for `batch` upper-triangular matrices (element strides strideS / strideW).
+vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
+                                   int batch, void *ws)
 {
     Arena ar(ws);
     const int nblk = (n + TBK - 1) / TBK;
-    double *Dall = ar.take<double>((size_t)nblk * TBK * TBK);
-    double *Tmp = ar.take<double>((size_t)n * TBK);
+    const size_t strideD = (size_t)nblk * TBK * TBK, strideT = (size_t)n * TBK;
+    double *Dall = ar.take<double>((size_t)batch * strideD);
+    double *Tmp = ar.take<double>((size_t)batch * strideT);
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, W, ldW, n);
+    hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, s, W, ldW, n, strideW);
     const size_t dlds = (size_t)(TBK * (TBK + 1) + TBK * TBK) * 8;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk), dim3(64), dlds, s, S, ldS, n, Dall);
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), dlds, s, S, ldS, n, Dall, strideS, strideD);
     for (int j0 = 0; j0 < n; j0 += TBK) {
         const int jb = (n - j0) < TBK ? (n - j0) : TBK;
         const double *D = Dall + (size_t)(j0 / TBK) * TBK * TBK;
-        hipLaunchKernelGGL(copy_block_kernel, dim3(1, jb), dim3(64), 0, s, D, TBK, W + (size_t)j0 * ldW + j0, ldW, jb, jb, 1.0);
+        hipLaunchKernelGGL(copy_block_kernel, dim3(1, jb, batch), dim3(64), 0, s, D, TBK, W + (size_t)j0 * ldW + j0, ldW, jb, jb, 1.0, strideD, strideW);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (j0 == 0) continue;
         GemmDesc g1;                       // Tmp = W[0:j0,0:j0] * S[0:j0, J]
         g1.M = j0; g1.N = jb; g1.K = j0; g1.transA = false; g1.transB = false; g1.amode = A_UPPER;
-        g1.A = W; g1.lda = ldW; g1.B = S + (size_t)j0 * ldS; g1.ldb = ldS; g1.C = Tmp; g1.ldc = n;
+        g1.A = W; g1.lda = ldW; g1.strideA = strideW; g1.B = S + (size_t)j0 * ldS; g1.ldb = ldS; g1.strideB = strideS;
+        g1.C = Tmp; g1.ldc = n; g1.strideC = strideT; g1.batch = batch;
         VSLAM_TRY(gemm_f64(ctx, g1));
         GemmDesc g2;                       // W[0:j0, J] = -Tmp * D
         g2.M = j0; g2.N = jb; g2.K = jb; g2.transA = false; g2.transB = false; g2.b_upper = true; g2.alpha = -1.0;
-        g2.A = Tmp; g2.lda = n; g2.B = D; g2.ldb = TBK; g2.C = W + (size_t)j0 * ldW; g2.ldc = ldW;
+        g2.A = Tmp; g2.lda = n; g2.strideA = strideT; g2.B = D; g2.ldb = TBK; g2.strideB = strideD;
+        g2.C = W + (size_t)j0 * ldW; g2.ldc = ldW; g2.strideC = strideW; g2.batch = batch;
         VSLAM_TRY(gemm_f64(ctx, g2));
     }
     return VSLAM_OK;
+}
+
+vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws)
+{
+    return trtri_upper_batch_dev(ctx, S, n, ldS, 0, W, ldW, 0, 1, ws);
 }
 
 // Vector solves with the upper-triangular S, one launch per 64-wide diagonal block: every
