@@ -6,6 +6,8 @@
 
 #include "common.hpp"
 
+#include <cmath>
+
 namespace vslam {
 
 // v of lane l (l wave-uniform) as a wave-uniform value: two v_readlane, no LDS round trip.
@@ -106,6 +108,14 @@ vslam_status cost_eval_dev(vslam_ctx *ctx, const CamK &k, double sigma, CostDevi
 // (newton.hip).  `ws` holds newton_ws_bytes(n) bytes beyond the CostDevice carve-up; *status_out
 // is 0 when the results were produced, 1 when an iterate's Hessian was not positive definite
 // (outputs are then meaningless and the caller takes the eigenvalue route).
+// Stopping rule of the multiplier iteration on the Cholesky routes, next to the reference's |ff| < sqrt(eps)
+// with ff = 1/Delta - 1/|p| (src/fmin.cpp:118-126).  Once the trust region has shrunk (Delta << 1) that
+// absolute test asks for more digits than ff has, and the reference then simply runs its 20 Newton steps,
+// which cost nothing in the eigenbasis; here each step is a factorisation.  When |p| matches Delta to
+// 1e-10 relative, the Newton step taken from that ff lands within rounding of the limit (quadratic
+// convergence), which is where the reference's remaining steps stay, flipping the last bits.
+inline bool trs_multiplier_settled(double ff, double Delta) { return std::fabs(ff) * Delta < 1e-10; }
+
 size_t newton_ws_bytes(int n);
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active);

@@ -304,9 +304,11 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
                 VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
                 const double ppn = std::sqrt(hd[0]), dpp = hd[1];
                 const double ff = 1 / Delta - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);   // d|p|/dlam = -p'(H+lam I)^-1 p / |p|
-                lam = std::max(0.0, lam - ff / gg);
+                const double lam_new = std::max(0.0, lam - ff / gg);
+                if (lam_new == lam) break;      // same multiplier, same factor and p: the remaining steps would change nothing
+                lam = lam_new;
                 VSLAM_TRY(factor_and_step(lam));
-                if (std::fabs(ff) < sqrteps) break;
+                if (std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta)) break;
             }
         }
         // ---- src/fmin.hpp:54-105 ----

@@ -340,9 +340,14 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 if (m[b]) {
                     const double ppn = std::sqrt(hd[(size_t)4 * b]), dpp = hd[(size_t)4 * b + 1];
                     const double ff = 1 / Delta[b] - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);
-                    lam[b] = std::max(0.0, lam[b] - ff / gg);
-                    stop[b] = std::fabs(ff) < sqrteps;
+                    const double lam_new = std::max(0.0, lam[b] - ff / gg);
+                    // see trs_multiplier_settled() in linalg.hpp
+                    stop[b] = std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta[b]);
+                    if (lam_new == lam[b]) { stop[b] = 1; m[b] = 0; }       // same multiplier: nothing to refactor
+                    lam[b] = lam_new;
                 }
+            if (!any(m)) break;
+            VSLAM_TRY(send_mask(m));
             VSLAM_TRY(factor_and_step());
             for (int b = 0; b < B; ++b)
                 if (stop[b]) m[b] = 0;
