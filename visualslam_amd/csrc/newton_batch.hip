@@ -78,13 +78,29 @@ __global__ __launch_bounds__(BK_T) void bk_trsv_kernel(const double *S, int ldS,
         }
         __syncthreads();
         if (trans) {
-            for (int j = i0 + ib + tid; j < n; j += BK_T) {
-                const double *col = Sb + (size_t)j * ldS + i0;
-                double s0 = 0.0, s1 = 0.0;
-                int l = 0;
-                for (; l + 2 <= ib; l += 2) { s0 += col[l] * xs[l]; s1 += col[l + 1] * xs[l + 1]; }
-                if (l < ib) s0 += col[l] * xs[l];
-                z[j] -= s0 + s1;
+            // later columns j: z[j] -= S[i0.., j] . x.  Eight lanes share a column, each holding the rows
+            // 16 q + 2 sub + {0, 1}, so that one load instruction of the wave covers whole cache lines of
+            // eight columns (a thread per column would touch 64 lines per instruction).  Only full blocks
+            // have later columns, so all 64 rows exist.
+            const int sub = tid & 7, grp = tid >> 3;
+            double xr[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xr[2 * q] = xs[16 * q + 2 * sub]; xr[2 * q + 1] = xs[16 * q + 2 * sub + 1]; }
+            for (int j0 = i0 + ib; j0 < n; j0 += BK_T / 8) {
+                const int j = j0 + grp;
+                double sum = 0.0;
+                if (j < n) {
+                    const double *col = Sb + (size_t)j * ldS + i0 + 2 * sub;
+                    double v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] = col[16 * q]; v[2 * q + 1] = col[16 * q + 1]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += v[q] * xr[q];
+                }
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sum += __shfl_xor(sum, 4, 64);
+                if (sub == 0 && j < n) z[j] -= sum;
             }
         } else {
             for (int i = tid; i < i0; i += BK_T) {
