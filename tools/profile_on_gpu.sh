@@ -7,7 +7,7 @@ R="$GRAFT_REPO_ROOT"
 OUT="$R/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/bench" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --steps 20 --warmup 3 > "$OUT/bench.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/bench" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-dense --steps 20 --warmup 3 > "$OUT/bench.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- python3 "$R/tools/run_loglik.py" 512 150 3 > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o write -- python3 "$R/tools/run_loglik.py" 512 150 3 > "$OUT/write.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d "$OUT/corner_sq" -o sq -- python3 "$R/tools/run_corner.py" 64 3 > "$OUT/corner_sq.log" 2>&1 || exit 1
