@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int
             const int row = kb + r;
             const double dkk = readlane_f64(acc[r], row);
             if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
-            const double d = sqrt(dkk);
-            const double u = (lane == row) ? d : acc[r] / d;     // row `row` of U (meaningful for lanes >= row)
+            const double inv = rsqrt(dkk);                       // one reciprocal square root per row instead of a square root and a division
+            const double u = (lane == row) ? dkk * inv : acc[r] * inv;     // row `row` of U (meaningful for lanes >= row)
             U[row * PLD + lane] = u;
 #pragma unroll
             for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
@@ -97,17 +97,20 @@ __global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int 
 #pragma unroll
         for (int j = 0; j < 16; ++j) Ut[(cb + j) * CLD + lane] = u[j];
     }
+    __shared__ double rdiag[CB];
     double x[CB];
     double *colx = A + (size_t)(c0 + (lane < nc ? lane : 0)) * lda + j0;
 #pragma unroll
     for (int k = 0; k < CB; ++k) x[k] = colx[k];
+    __syncthreads();
+    rdiag[lane] = 1.0 / Ut[lane * CLD + lane];                  // all 64 reciprocals at once: the chain below only multiplies
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < CB; ++k) {
         double s = x[k];
 #pragma unroll
         for (int l = 0; l < k; ++l) s -= Ut[k * CLD + l] * x[l];
-        x[k] = s / Ut[k * CLD + k];
+        x[k] = s * rdiag[k];
     }
     if (lane < nc) {
 #pragma unroll
