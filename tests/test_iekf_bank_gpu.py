@@ -19,7 +19,7 @@ def _bank(L, B, seed0, perturb=True):
     return scs, np.stack(mus)
 
 
-@pytest.mark.parametrize("L,B", [(5, 3), (50, 6), (150, 4)])
+@pytest.mark.parametrize("L,B", [(5, 3), (50, 6), (150, 4), (500, 2)])
 def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
     import torch
     from visualslam_amd import api
