@@ -1,5 +1,7 @@
 """Corner front-end leg of bench.py: 1080p frames/s (Harris + Shi-Tomasi keypoint
 lists per frame: response -> 3x3 NMS -> threshold -> score-sorted top-K)."""
+import json
+import os
 import time
 
 import numpy as np
@@ -51,12 +53,17 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
     kp = float(counts.sum()) / F
     alg = (W * H + 12.0 * kp) * F
     achieved = alg / (dev_ms * 1e-3) / 1e9
+    traffic = None                      # HBM bytes per step from the committed counter passes (64-frame step)
+    tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_corner.json")
+    if F == 64 and os.path.exists(tfile):
+        with open(tfile) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_step")
     res = {
         "metric": "corner-detect frames/s (1080p)", "value": F * args.steps * world / elapsed, "unit": "frames/s",
         "frames_per_gpu_per_step": F, "ms_per_step": elapsed / args.steps * 1e3,
         "mean_keypoints_per_frame": {"harris": float(counts[:, 0].mean()), "shi_tomasi": float(counts[:, 1].mean())},
         "roofline": {"bound": "hbm", "kernel": "corner_strip_kernel<3> + sort/merge/emit", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_step": alg, "device_ms_per_step": dev_ms},
         "dtype": "u8 -> int32 structure tensor -> f32 response",
     }

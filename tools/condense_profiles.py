@@ -65,6 +65,25 @@ def main():
     with open(os.path.join(DST, "traffic_point_loglik.json"), "w") as f:
         json.dump(traffic, f, indent=1)
 
+    cf_db, cw_db = os.path.join(SRC, "corner_fetch", "fetch_results.db"), os.path.join(SRC, "corner_write", "write_results.db")
+    if os.path.exists(cf_db) and os.path.exists(cw_db):
+        names = ["corner_strip_kernel", "corner_tile_kernel", "sort_chunk_kernel", "merge_chunks_kernel", "emit_features_kernel"]
+        cf, cw = counters(cf_db, names), counters(cw_db, names)
+        ck, ctotal = {}, 0.0
+        for k in cf:
+            fkb, wkb = cf[k]["FETCH_SIZE"], cw.get(k, {}).get("WRITE_SIZE", 0.0)
+            per_step = cf[k]["launches"] / 3.0          # run_corner.py 64 3 = three steps
+            ck[k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "launches_per_step": per_step,
+                     "bytes_per_step": (2 * fkb + wkb) * 1024 * per_step}
+            ctotal += ck[k]["bytes_per_step"]
+        with open(os.path.join(DST, "traffic_corner.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/run_corner.py 64 3",
+                       "workload": "64 frames 1920x1080, both detectors, keypoints out (one step = strip + sort + merge + emit kernels)",
+                       "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE taken as is; units KB",
+                       "kernels": ck, "hbm_bytes_per_step": ctotal,
+                       "algorithmic_bytes_per_step": 64 * 1920 * 1080 + 12 * 64 * (1873 + 6265)}, f, indent=1)
+        print("corner HBM bytes per step %.0f" % ctotal)
+
     sq = counters(os.path.join(SRC, "corner_sq", "sq_results.db"), ["corner_strip_kernel", "corner_tile_kernel"])
     with open(os.path.join(DST, tag + "_corner_sq_counters.json"), "w") as f:
         json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU "
