@@ -89,6 +89,13 @@ def _tp(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _tpc(t):
+    """Device pointer of a tensor that the C ABI addresses as one dense block (no stride arguments)."""
+    if t is not None and not t.is_contiguous():
+        raise ValueError("libvslam_hip needs a contiguous tensor here (got strides %s for shape %s)" % (tuple(t.stride()), tuple(t.shape)))
+    return _tp(t)
+
+
 # ------------------------------------------------------------------ host-pointer calls
 def project(ctx, cam, x, j0=0, L=None):
     x = _f64(x)
@@ -255,8 +262,8 @@ def measurement_update_iekf_batch_dev(ctx, cam, mu, S, y, visible, sigma, mu_pos
     code = np.zeros(B, dtype=np.int32)
     iters = np.zeros(B, dtype=np.int32)
     status = np.zeros(B, dtype=np.int32)
-    check(ctx._L.vslam_measurement_update_iekf_batch_dev(ctx.ptr, C.byref(cam), _tp(mu), _tp(S), n, B, _tp(y), _tp(visible),
-                                                         float(sigma), _tp(mu_post), _tp(S_post), _p(code), _p(iters),
+    check(ctx._L.vslam_measurement_update_iekf_batch_dev(ctx.ptr, C.byref(cam), _tpc(mu), _tpc(S), n, B, _tpc(y), _tpc(visible),
+                                                         float(sigma), _tpc(mu_post), _tpc(S_post), _p(code), _p(iters),
                                                          _p(status)), ctx.ptr)
     return code, iters, status
 
@@ -365,7 +372,7 @@ def remove_landmark_dev(ctx, mu, S, j, mu_out, S_out, s_is_upper=True):
     """torch f64 tensors on the GPU: mu (n), S column-major n x n (i.e. the tensor holds S^T), mu_out (n-3),
     S_out column-major (n-3) x (n-3); outputs must not overlap the inputs."""
     n = mu.shape[0]
-    check(ctx._L.vslam_remove_landmark_dev(ctx.ptr, _tp(mu), _tp(S), n, n, int(j), _tp(mu_out), _tp(S_out), max(n - 3, 1),
+    check(ctx._L.vslam_remove_landmark_dev(ctx.ptr, _tpc(mu), _tpc(S), n, n, int(j), _tpc(mu_out), _tpc(S_out), max(n - 3, 1),
                                            int(bool(s_is_upper))), ctx.ptr)
 
 
