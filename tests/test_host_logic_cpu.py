@@ -39,6 +39,23 @@ def test_sym_eig_host(L, n):
     assert np.max(np.abs(H @ Q - Q * v)) <= 1e-11 * max(1.0, np.max(np.abs(w)))
 
 
+def test_sym_eig_host_baseline_variant_agrees(L):
+    """The solver is built for the baseline x86-64 instruction set and for AVX2+FMA; the dispatcher picks one
+    per CPU.  Both must give the same decomposition up to rounding (and eigenvector signs)."""
+    n = 90
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n))
+    H = np.asfortranarray(A + A.T)
+    Q1, v1 = _eig(L, H)
+    Q0, v0 = np.zeros((n, n), order="F"), np.zeros(n)
+    L.vslam_debug_sym_eig_base.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.vslam_debug_sym_eig_base.restype = None
+    L.vslam_debug_sym_eig_base(H.ctypes.data, n, Q0.ctypes.data, v0.ctypes.data)
+    assert np.max(np.abs(v0 - v1)) <= 1e-12 * np.max(np.abs(v1))
+    assert np.max(np.abs(np.abs(Q0.T @ Q1) - np.eye(n))) <= 1e-9
+    assert np.max(np.abs(H @ Q0 - Q0 * v0)) <= 1e-11 * np.max(np.abs(v0))
+
+
 def test_sym_eig_host_repeated_and_diagonal(L):
     Q, v = _eig(L, np.diag([3.0, 1.0, 1.0, 2.0]))
     assert v.tolist() == [1.0, 1.0, 2.0, 3.0]

@@ -132,6 +132,8 @@ extern "C" vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver)
 
 // Test hook (not part of the public header): the host eigensolver of the eigenvalue route.
 extern "C" void vslam_debug_sym_eig(const double *H, int n, double *Q, double *v) { sym_eig_host(H, n, Q, v); }
+// Test hook: the baseline-instruction-set variant, whatever the CPU supports.
+extern "C" void vslam_debug_sym_eig_base(const double *H, int n, double *Q, double *v) { sym_eig_base(H, n, Q, v); }
 // Test hook: the trust-region subproblem in the eigenbasis (src/fmin.cpp:40-131); returns trs's code.
 extern "C" int vslam_debug_trs(const double *Q, const double *v, const double *g, int n, double D, double *p)
 {
