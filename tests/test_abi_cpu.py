@@ -36,6 +36,58 @@ def test_camera_xml_reader(cam_dict):
         api.camera_from_xml("/nonexistent/camera.xml")
 
 
+def _camera_xml_text():
+    from visualslam_amd import synthetic as syn
+    with open(syn.CAMERA_XML) as fh:
+        return fh.read()
+
+
+@pytest.mark.parametrize("case", ["truncated", "matrix_short", "not_a_number", "no_distortion", "too_many_coefficients",
+                                  "no_flag", "zero_width", "negative_focal", "nan_focal", "empty"])
+def test_camera_xml_reader_rejects_malformed_files(tmp_path, case):
+    """Wire-format hardening of the calibration reader (the reference reads the file with cv::FileStorage,
+    src/cameraModel.cpp:93-100): a damaged file is an I/O error, never a half-filled camera."""
+    import re
+    from visualslam_amd import api
+    txt = _camera_xml_text()
+    data = re.compile(r"(<camera_matrix.*?<data>)(.*?)(</data>)", re.S)
+    if case == "truncated":
+        txt = txt[: len(txt) // 2]
+    elif case == "matrix_short":
+        txt = data.sub(lambda m: m.group(1) + " ".join(m.group(2).split()[:8]) + m.group(3), txt, count=1)
+    elif case == "not_a_number":
+        txt = data.sub(lambda m: m.group(1) + m.group(2).replace(m.group(2).split()[0], "9.05e+02x", 1) + m.group(3), txt, count=1)
+    elif case == "no_distortion":
+        txt = re.sub(r"<distortion_coefficients.*?</distortion_coefficients>", "", txt, flags=re.S)
+    elif case == "too_many_coefficients":
+        txt = re.sub(r"(<distortion_coefficients.*?<data>)(.*?)(</data>)", lambda m: m.group(1) + " ".join(["0.1"] * 13) + m.group(3), txt, count=1, flags=re.S)
+    elif case == "no_flag":
+        txt = re.sub(r"<flag>.*?</flag>", "", txt, flags=re.S)
+    elif case == "zero_width":
+        txt = re.sub(r"<imageSize>.*?</imageSize>", "<imageSize>0 1080</imageSize>", txt, flags=re.S)
+    elif case == "negative_focal":
+        txt = data.sub(lambda m: m.group(1) + "-" + m.group(2).lstrip() + m.group(3), txt, count=1)
+    elif case == "nan_focal":
+        txt = data.sub(lambda m: m.group(1) + " ".join(["nan"] + m.group(2).split()[1:]) + m.group(3), txt, count=1)
+    elif case == "empty":
+        txt = ""
+    path = tmp_path / "camera.xml"
+    path.write_text(txt)
+    with pytest.raises(api.VslamError):
+        api.camera_from_xml(path)
+
+
+def test_camera_xml_reader_accepts_reformatted_file(tmp_path):
+    """Whitespace and line breaks inside the data blocks do not matter."""
+    import re
+    from visualslam_amd import api, synthetic as syn
+    txt = re.sub(r"[ \t]+", "  ", _camera_xml_text()).replace("\n", "\n\n")
+    path = tmp_path / "camera.xml"
+    path.write_text(txt)
+    a, b = api.camera_from_xml(path), api.camera_from_xml(syn.CAMERA_XML)
+    assert bytes(a) == bytes(b)
+
+
 def test_struct_layouts_match_header():
     from visualslam_amd import _lib
     assert ctypes.sizeof(_lib.Camera) == 152

@@ -129,6 +129,10 @@ vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *k)
 {
     const int RATIONAL = 0x4000, THIN = 0x8000;
     if (!cam) return fail(ctx, VSLAM_ERR_ARG, "camera is null");
+    if (!(cam->fx > 0.0 && cam->fy > 0.0 && std::isfinite(cam->fx) && std::isfinite(cam->fy) && std::isfinite(cam->cx) && std::isfinite(cam->cy)))
+        return fail(ctx, VSLAM_ERR_ARG, "camera: focal lengths must be positive and finite (fx=%g fy=%g cx=%g cy=%g)", cam->fx, cam->fy, cam->cx, cam->cy);
+    if (cam->width < 1 || cam->height < 1 || !(cam->fov_deg > 0.0 && cam->fov_deg < 360.0))
+        return fail(ctx, VSLAM_ERR_ARG, "camera: image size %d x %d, field of view %g deg", cam->width, cam->height, cam->fov_deg);
     if (cam->flag & ~(RATIONAL | THIN))
         return fail(ctx, VSLAM_ERR_UNSUPPORTED, "calibration flag %d: only RATIONAL|THIN_PRISM are supported", cam->flag);
     bool rational = (cam->flag & RATIONAL) == RATIONAL, thin = (cam->flag & THIN) == THIN;
@@ -286,8 +290,14 @@ vslam_status vslam_camera_from_xml(const char *path, vslam_camera *cam)
     if (!xml_block(txt, "flag", &body) || !xml_numbers(body, &v) || v.size() != 1) return VSLAM_ERR_IO;
     cam->flag = int32_t(v[0]);
     if (!xml_block(txt, "imageSize", &body) || !xml_numbers(body, &v) || v.size() != 2) return VSLAM_ERR_IO;
+    if (!(v[0] >= 1.0 && v[0] <= 65536.0 && v[1] >= 1.0 && v[1] <= 65536.0)) return VSLAM_ERR_IO;
     cam->width = int32_t(v[0]);
     cam->height = int32_t(v[1]);
+    // a calibration that cannot be one: non-finite entries or a non-positive focal length
+    if (!(std::isfinite(cam->fx) && std::isfinite(cam->fy) && std::isfinite(cam->cx) && std::isfinite(cam->cy)) || cam->fx <= 0.0 || cam->fy <= 0.0)
+        return VSLAM_ERR_IO;
+    for (int i = 0; i < 12; ++i)
+        if (!std::isfinite(cam->d[i])) return VSLAM_ERR_IO;
     return VSLAM_OK;
 }
 
