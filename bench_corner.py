@@ -67,8 +67,36 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
                      "algorithmic_bytes_per_step": alg, "device_ms_per_step": dev_ms},
         "dtype": "u8 -> int32 structure tensor -> f32 response",
     }
+    # FAST-9/16 (first stage of cv::ORB::detect) on the same frames: threshold 20 as the reference configures it
+    fout = torch.zeros((F, cap, 3), dtype=torch.int32, device=dev)
+    fcnt = torch.zeros(F, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        api.fast9_detect_batch_dev(ctx, frames, W, H, W, W * H, F, 20, True, cap, fout, cap, fcnt)
+    torch.cuda.synchronize()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    freps = 20
+    f0.record(stream)
+    for _ in range(freps):
+        api.fast9_detect_batch_dev(ctx, frames, W, H, W, W * H, F, 20, True, cap, fout, cap, fcnt)
+    f1.record(stream)
+    torch.cuda.synchronize()
+    fast_ms = f0.elapsed_time(f1) / freps
+    fk = float(fcnt.clamp(min=0).sum().item()) / F
+    falg = (W * H + 12.0 * fk) * F
+    res["fast9"] = {"value": F / (fast_ms * 1e-3), "unit": "frames/s", "ms_per_step": fast_ms, "threshold": 20, "nonmax": True,
+                    "mean_keypoints_per_frame": fk, "overflowed_frames": int((fcnt < 0).sum().item()),
+                    "roofline": {"bound": "hbm", "kernel": "fast9_tile_kernel + sort/merge/emit", "achieved": falg / (fast_ms * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": falg / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_step": falg}}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            orc.fast9_detect(base[reps % len(base)], 20, True)
+            reps += 1
+        res["fast9"]["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
+                                        "sample": "%d synthetic 1080p frames, oracle scalar C" % reps}
         op = orc.corner_params(harris_thresh=1e-4, shi_thresh=1e-3, max_features=10000)
         t0 = time.perf_counter()
         reps = 0

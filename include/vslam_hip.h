@@ -302,6 +302,20 @@ vslam_status vslam_corner_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, 
                                            const vslam_corner_params *params, int detector,
                                            vslam_feature *out, int cap, int32_t *count);
 
+/* FAST-9/16 with non-maximum suppression, the first stage of cv::ORB::detect as the reference configures
+ * it (src/imagefeatures.cpp:73-87, fastThreshold 20).  OpenCV's code is not part of the reference, so the
+ * contract is the published segment test with OpenCV's conventions: a pixel is a corner iff 9 contiguous
+ * pixels of the 16-pixel radius-3 circle are all brighter than I_p + threshold or all darker than
+ * I_p - threshold; score = the largest threshold at which it still is; pixels within 3 of the border
+ * never are; nonmax != 0 keeps a corner only if it is stronger than every neighbouring corner.  Output
+ * as for vslam_corner_detect (sorted by score, ties by y then x; same capacity limits). */
+vslam_status vslam_fast9_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax,
+                                int max_features, vslam_feature *out, int cap, int32_t *count);
+/* Device-pointer batch: frame f at gray + f*stride_frame, out + f*cap, count[f] (-1: more than 65536 corners). */
+vslam_status vslam_fast9_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                          int frames, int threshold, int nonmax, int max_features,
+                                          vslam_feature *out, int cap, int32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,6 +328,23 @@ def corner_detect(gray, params, which, cap=None):
     return out[:n].copy()
 
 
+def fast9_strength(gray, x, y):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    return int(_lib.orc_fast9_strength(_b(gray), w, h, w, int(x), int(y)))
+
+
+def fast9_detect(gray, threshold=20, nonmax=True, max_features=16384, cap=None):
+    """FAST-9/16 keypoints (first stage of cv::ORB::detect, reference src/imagefeatures.cpp:73-87), sorted by score."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    cap = max_features if cap is None else cap
+    out = np.zeros(cap, dtype=FEATURE_DTYPE)
+    n = _lib.orc_fast9_detect(_b(gray), w, h, w, int(threshold), int(bool(nonmax)), int(max_features),
+                              out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n].copy()
+
+
 def normcdf(z):
     return float(_lib.orc_normcdf(float(z)))
 

@@ -1384,3 +1384,69 @@ int orc_corner_detect(const uint8_t *gray, int w, int h, int stride,
     free(cand); free(resp);
     return nout;
 }
+
+
+/* ---- FAST-9 segment test (first stage of cv::ORB::detect as configured at src/imagefeatures.cpp:73-87:
+ * fastThreshold 20, FAST 9/16 with non-maximum suppression).  OpenCV is not in this build: the contract
+ * below restates the published detector (Rosten & Drummond) with OpenCV's conventions and is unpinned by
+ * the reference.
+ *   ring: the 16 pixels of the radius-3 Bresenham circle, clockwise from (0, +3);
+ *   strength s(p) = max over the 16 arcs of 9 contiguous ring pixels of min over the arc of (I_q - I_p),
+ *                   and the same with (I_p - I_q); the larger of the two;
+ *   p is a corner iff s(p) > threshold (9 contiguous pixels all brighter than I_p + t or all darker than
+ *   I_p - t); its score is s(p) - 1, the largest threshold at which it is still a corner;
+ *   pixels closer than 3 to the image border are never corners;
+ *   nonmax: a corner is kept iff its strength exceeds that of every 8-neighbour that is a corner;
+ *   output sorted by score descending, ties by y then x ascending (feat_cmp). */
+static const int fast_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int fast_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+int orc_fast9_strength(const uint8_t *gray, int w, int h, int stride, int x, int y)
+{
+    if (x < 3 || y < 3 || x >= w - 3 || y >= h - 3) return 0;
+    int v = gray[x + (size_t)stride * y], d[16], best = 0;
+    for (int i = 0; i < 16; ++i) d[i] = (int)gray[(x + fast_dx[i]) + (size_t)stride * (y + fast_dy[i])] - v;
+    for (int pol = 0; pol < 2; ++pol)
+        for (int a = 0; a < 16; ++a) {
+            int m = 1 << 30;
+            for (int k = 0; k < 9; ++k) {
+                int q = pol ? -d[(a + k) & 15] : d[(a + k) & 15];
+                if (q < m) m = q;
+            }
+            if (m > best) best = m;
+        }
+    return best;
+}
+
+int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax, int max_features,
+                     orc_feature *out, int cap)
+{
+    size_t npx = (size_t)w * h;
+    int *st = (int *)calloc(npx, sizeof(int));
+    for (int y = 3; y < h - 3; ++y)
+        for (int x = 3; x < w - 3; ++x) {
+            int s = orc_fast9_strength(gray, w, h, stride, x, y);
+            st[x + (size_t)w * y] = s > threshold ? s : 0;
+        }
+    size_t cnt = 0, capc = 1024;
+    orc_feature *cand = (orc_feature *)malloc(capc * sizeof(orc_feature));
+    for (int y = 3; y < h - 3; ++y)
+        for (int x = 3; x < w - 3; ++x) {
+            int s = st[x + (size_t)w * y];
+            if (!s) continue;
+            int ok = 1;
+            if (nonmax)
+                for (int dy = -1; dy <= 1 && ok; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx)
+                        if ((dx || dy) && !(s > st[(x + dx) + (size_t)w * (y + dy)])) { ok = 0; break; }
+            if (!ok) continue;
+            if (cnt == capc) { capc *= 2; cand = (orc_feature *)realloc(cand, capc * sizeof(orc_feature)); }
+            cand[cnt].x = x; cand[cnt].y = y; cand[cnt].score = (float)(s - 1); ++cnt;
+        }
+    qsort(cand, cnt, sizeof(orc_feature), feat_cmp);
+    int lim = max_features < cap ? max_features : cap;
+    int nout = (int)(cnt < (size_t)lim ? cnt : (size_t)lim);
+    memcpy(out, cand, (size_t)nout * sizeof(orc_feature));
+    free(cand); free(st);
+    return nout;
+}

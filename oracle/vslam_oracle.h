@@ -184,6 +184,10 @@ void orc_corner_response(const uint8_t *gray, int w, int h, int stride,
  * descending (ties: y then x ascending), at most min(cap, max_features). */
 int orc_corner_detect(const uint8_t *gray, int w, int h, int stride,
                       const orc_corner_params *p, int which, orc_feature *out, int cap);
+/* FAST-9/16 (first stage of cv::ORB::detect, src/imagefeatures.cpp:73-87): strength of one pixel and the detector. */
+int orc_fast9_strength(const uint8_t *gray, int w, int h, int stride, int x, int y);
+int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax, int max_features,
+                     orc_feature *out, int cap);
 
 #ifdef __cplusplus
 }

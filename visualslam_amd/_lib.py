@@ -116,6 +116,8 @@ def _declare(L):
         "vslam_match_hamming_batch_dev": [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp, _i, _i, _vp, _vp],
         "vslam_corner_detect": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
         "vslam_corner_response": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _vp, _vp],
+        "vslam_fast9_detect": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+        "vslam_fast9_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
     }
     for name, args in sig.items():

@@ -325,6 +325,23 @@ def corner_detect(ctx, gray, params, detector=HARRIS, cap=None):
     return out[:int(cnt[0])].copy()
 
 
+def fast9_detect(ctx, gray, threshold=20, nonmax=True, max_features=16384, cap=None, stride=None):
+    """FAST-9/16 keypoints (first stage of cv::ORB::detect, reference src/imagefeatures.cpp:73-87), sorted by score."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    if stride is not None:                      # image is a window of `w_used` columns inside rows of `stride` bytes
+        w_used, row_bytes = stride
+        w, stride = w_used, row_bytes
+    else:
+        stride = w
+    cap = max_features if cap is None else cap
+    out = np.zeros(cap, dtype=FEATURE_DTYPE)
+    cnt = np.zeros(1, dtype=np.int32)
+    check(ctx._L.vslam_fast9_detect(ctx.ptr, _p(gray), w, h, stride, int(threshold), int(bool(nonmax)), int(max_features),
+                                    _p(out), cap, _p(cnt)), ctx.ptr)
+    return out[:int(cnt[0])].copy()
+
+
 def corner_response(ctx, gray, params):
     gray = np.ascontiguousarray(gray, dtype=np.uint8)
     h, w = gray.shape
@@ -383,6 +400,11 @@ def match_hamming_batch_dev(ctx, query, train, idx, dist=None, nt_each=None):
     check(ctx._L.vslam_match_hamming_batch_dev(ctx.ptr, _tp(query), nq * nb, nq, _tp(train), nt * nb, nt,
                                                _tp(nt_each) if nt_each is not None else None, nb, B, _tp(idx),
                                                _tp(dist) if dist is not None else None), ctx.ptr)
+
+
+def fast9_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, threshold, nonmax, max_features, out, cap, count):
+    check(ctx._L.vslam_fast9_detect_batch_dev(ctx.ptr, _tp(gray), w, h, stride, stride_frame, frames, int(threshold),
+                                              int(bool(nonmax)), int(max_features), _tp(out), cap, _tp(count)), ctx.ptr)
 
 
 def corner_detect_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, params, detector, out, cap, count):

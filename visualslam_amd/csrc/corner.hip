@@ -606,6 +606,94 @@ __global__ void emit_features_kernel(const uint64_t *cand, const int32_t *cand_c
     out[((size_t)f * ndet + d) * cap + i] = ft;
 }
 
+// ---- FAST-9/16 segment test (first stage of cv::ORB::detect as configured at reference
+// src/imagefeatures.cpp:73-87: fastThreshold 20, non-maximum suppression) -------------------------
+// strength s(p) = max over the 16 arcs of 9 contiguous pixels of the radius-3 circle of the arc's
+// minimum of (I_q - I_p), and the same for (I_p - I_q); corner iff s > threshold, score s - 1; with
+// nonmax a corner survives iff it is stronger than every neighbouring corner.  Integer work, equal to
+// the CPU oracle bit for bit.  One workgroup per 64 x 16 tile: image tile with a 4-pixel halo in LDS,
+// strengths of the tile and a 1-pixel ring in LDS, then suppression and one reservation per workgroup
+// in the frame's candidate list, which the sort / merge / emit kernels above finish.
+constexpr int FT_W = 64, FT_H = 16, FT_IW = FT_W + 8, FT_IH = FT_H + 8, FT_SW = FT_W + 2, FT_SH = FT_H + 2;
+
+struct FastArgs {
+    const uint8_t *gray; size_t stride_frame;
+    int w, h, stride, threshold, nonmax, tiles_x, frames;
+    uint64_t *cand;        // [frame][2][CAND_CAP], list 0 used
+    int32_t *cand_count;   // [frame][2]
+};
+
+__device__ __forceinline__ int fast9_strength(const int (&d)[16])
+{
+    int lo2[16], hi2[16], lo4[16], hi4[16], best = 0, worst = 255;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);      // min over ring pixels i .. i+8
+        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+        best = max(best, lo9);                                                    // brighter arc
+        worst = min(worst, hi9);                                                  // darker arc: its minimum of -d is -hi9
+    }
+    return max(best, -worst);
+}
+
+__global__ __launch_bounds__(256) void fast9_tile_kernel(FastArgs a)
+{
+    __shared__ uint8_t img[FT_IH][FT_IW + 4];
+    __shared__ int st[FT_SH][FT_SW + 1];
+    __shared__ uint64_t stage[FT_W * FT_H];
+    __shared__ int lcnt, gbase;
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x % a.frames, tile = blockIdx.x / a.frames;
+    const int x0 = (tile % a.tiles_x) * FT_W, y0 = (tile / a.tiles_x) * FT_H;
+    const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
+    const int w = a.w, h = a.h;
+    if (tid == 0) lcnt = 0;
+    for (int idx = tid; idx < FT_IH * FT_IW; idx += 256) {
+        const int ly = idx / FT_IW, lx = idx - ly * FT_IW, gx = x0 - 4 + lx, gy = y0 - 4 + ly;
+        img[ly][lx] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? gray[(size_t)gy * a.stride + gx] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < FT_SH * FT_SW; idx += 256) {
+        const int ly = idx / FT_SW, lx = idx - ly * FT_SW, px = x0 - 1 + lx, py = y0 - 1 + ly;
+        int s = 0;
+        if (px >= 3 && py >= 3 && px < w - 3 && py < h - 3) {
+            const int cy = ly + 3, cx = lx + 3, v = img[cy][cx];
+            int d[16];
+            d[0] = img[cy + 3][cx] - v;      d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
+            d[4] = img[cy][cx + 3] - v;      d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
+            d[8] = img[cy - 3][cx] - v;      d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
+            d[12] = img[cy][cx - 3] - v;     d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
+            s = fast9_strength(d);
+            if (s <= a.threshold) s = 0;
+        }
+        st[ly][lx] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < FT_W * FT_H; idx += 256) {
+        const int ly = idx / FT_W, lx = idx - ly * FT_W, px = x0 + lx, py = y0 + ly;
+        if (px >= w || py >= h) continue;
+        const int s = st[ly + 1][lx + 1];
+        if (s == 0) continue;
+        bool keep = true;
+        if (a.nonmax) {
+            const int nb = max(max(max(st[ly][lx], st[ly][lx + 1]), max(st[ly][lx + 2], st[ly + 1][lx])),
+                               max(max(st[ly + 1][lx + 2], st[ly + 2][lx]), max(st[ly + 2][lx + 1], st[ly + 2][lx + 2])));
+            keep = s > nb;
+        }
+        if (keep) stage[atomicAdd(&lcnt, 1)] = make_key((float)(s - 1), px, py);
+    }
+    __syncthreads();
+    if (tid == 0) gbase = lcnt ? atomicAdd(a.cand_count + (size_t)frame * 2, lcnt) : 0;
+    __syncthreads();
+    uint64_t *dst = a.cand + (size_t)frame * 2 * CAND_CAP;
+    for (int i = tid; i < lcnt; i += 256)
+        if (gbase + i < CAND_CAP) dst[gbase + i] = stage[i];
+}
+
 static size_t tile_lds_bytes(int bs)
 {
     const int hb = bs / 2, halo = hb + 2;
@@ -689,6 +777,37 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     hipLaunchKernelGGL(emit_features_kernel, dim3((lim + 255) / 256, frames, ndet), dim3(256), 0, s, a.cand, a.cand_count,
                        det_first, ndet, cap, p->max_features, out, count);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+static vslam_status launch_fast9(vslam_ctx *ctx, FastArgs a, int frames, int max_features, vslam_feature *out, int cap, int32_t *count, void *ws)
+{
+    Arena ar(ws);
+    a.cand = ar.take<uint64_t>((size_t)frames * 2 * CAND_CAP);
+    a.cand_count = ar.take<int32_t>((size_t)frames * 2);
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(a.cand_count, 0, (size_t)frames * 2 * 4, s));
+    a.tiles_x = (a.w + FT_W - 1) / FT_W; a.frames = frames;
+    const size_t tiles = (size_t)a.tiles_x * ((a.h + FT_H - 1) / FT_H) * frames;
+    if (tiles > 0x7fffffffu) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: too many tiles for one launch");
+    hipLaunchKernelGGL(fast9_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 1);
+    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
+        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s,
+                           a.cand, a.cand_count, step, 1);
+    const int lim = cap < max_features ? cap : max_features;
+    hipLaunchKernelGGL(emit_features_kernel, dim3((lim + 255) / 256, frames, 1), dim3(256), 0, s, a.cand, a.cand_count,
+                       0, 1, cap, max_features, out, count);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+static vslam_status check_fast9(vslam_ctx *ctx, int w, int h, int stride, int threshold, int max_features)
+{
+    if (w < 7 || h < 7 || stride < w) return fail(ctx, VSLAM_ERR_SHAPE, "fast9_detect: image %dx%d (stride %d) too small", w, h, stride);
+    if (w > 65535 || h > 65535) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: image side exceeds 65535");
+    if (threshold < 0 || threshold > 254) return fail(ctx, VSLAM_ERR_ARG, "fast9_detect: threshold %d outside [0,254]", threshold);
+    if (max_features < 1 || max_features > SORT_S) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: max_features %d outside [1,%d]", max_features, SORT_S);
     return VSLAM_OK;
 }
 
@@ -784,6 +903,50 @@ extern "C" vslam_status vslam_corner_detect(vslam_ctx *ctx, const uint8_t *gray,
         if (hc[d] > 0)
             VSLAM_HIP_TRY(ctx, hipMemcpy(out + (size_t)d * cap, dout + (size_t)d * cap, (size_t)hc[d] * sizeof(vslam_feature), hipMemcpyDeviceToHost));
     }
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_fast9_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                                     int frames, int threshold, int nonmax, int max_features,
+                                                     vslam_feature *out, int cap, int32_t *count)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "fast9_detect: null pointer or cap < 1");
+    if (frames < 1 || frames > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "fast9_detect: frames=%d out of range", frames);
+    VSLAM_TRY(check_fast9(ctx, w, h, stride, threshold, max_features));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    VSLAM_TRY(ws_reserve(ctx, detect_ws_bytes(frames)));
+    FastArgs a;
+    a.gray = gray; a.stride_frame = stride_frame; a.w = w; a.h = h; a.stride = stride; a.threshold = threshold; a.nonmax = nonmax ? 1 : 0;
+    return launch_fast9(ctx, a, frames, max_features, out, cap, count, ctx->ws);
+}
+
+extern "C" vslam_status vslam_fast9_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax,
+                                           int max_features, vslam_feature *out, int cap, int32_t *count)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "fast9_detect: null pointer or cap < 1");
+    VSLAM_TRY(check_fast9(ctx, w, h, stride, threshold, max_features));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    const size_t img_bytes = (size_t)stride * h, out_bytes = (size_t)cap * sizeof(vslam_feature);
+    VSLAM_TRY(ws_reserve(ctx, detect_ws_bytes(1) + Arena::pad(img_bytes) + Arena::pad(out_bytes) + Arena::pad(8)));
+    Arena ar(ctx->ws);
+    void *dws = ar.take<char>(detect_ws_bytes(1));
+    uint8_t *dimg = ar.take<uint8_t>(img_bytes);
+    vslam_feature *dout = ar.take<vslam_feature>((size_t)cap);
+    int32_t *dcount = ar.take<int32_t>(2);
+    VSLAM_TRY(h2d(ctx, dimg, gray, img_bytes));
+    FastArgs a;
+    a.gray = dimg; a.stride_frame = 0; a.w = w; a.h = h; a.stride = stride; a.threshold = threshold; a.nonmax = nonmax ? 1 : 0;
+    VSLAM_TRY(launch_fast9(ctx, a, 1, max_features, dout, cap, dcount, dws));
+    int32_t hc = 0;
+    VSLAM_TRY(d2h(ctx, &hc, dcount, 4));
+    VSLAM_TRY(stream_sync(ctx));
+    if (hc < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: more than %d corners; raise the threshold", CAND_CAP);
+    *count = hc;
+    if (hc > 0) VSLAM_HIP_TRY(ctx, hipMemcpy(out, dout, (size_t)hc * sizeof(vslam_feature), hipMemcpyDeviceToHost));
     return VSLAM_OK;
 }
 
