@@ -58,6 +58,17 @@ def test_fast9_cap_and_max_features(ctx):
     assert _same(api.fast9_detect(ctx, img, 25, True, max_features=100, cap=9), full[:9])
 
 
+def test_fast9_dense_corners_per_tile(ctx):
+    """More corners in one 64 x 32 tile than its staging buffer holds (512): the rest goes the slow way."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (70, 140), dtype=np.uint8)
+    want = orc.fast9_detect(img, 3, False)
+    assert len(want) > 3000
+    assert _same(api.fast9_detect(ctx, img, 3, False), want)
+
+
 def test_fast9_capacity(ctx):
     """A frame with more corners than a candidate list holds is an error, not a silent truncation."""
     from visualslam_amd import api, synthetic as syn

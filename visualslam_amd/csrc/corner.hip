@@ -614,7 +614,7 @@ __global__ void emit_features_kernel(const uint64_t *cand, const int32_t *cand_c
 // the CPU oracle bit for bit.  One workgroup per 64 x 16 tile: image tile with a 4-pixel halo in LDS,
 // strengths of the tile and a 1-pixel ring in LDS, then suppression and one reservation per workgroup
 // in the frame's candidate list, which the sort / merge / emit kernels above finish.
-constexpr int FT_W = 64, FT_H = 16, FT_IW = FT_W + 8, FT_IH = FT_H + 8, FT_SW = FT_W + 2, FT_SH = FT_H + 2;
+constexpr int FT_W = 64, FT_H = 32, FT_IW = FT_W + 8, FT_IH = FT_H + 8, FT_SW = FT_W + 2, FT_SH = FT_H + 2;
 
 struct FastArgs {
     const uint8_t *gray; size_t stride_frame;
@@ -642,9 +642,10 @@ __device__ __forceinline__ int fast9_strength(const int (&d)[16])
 
 __global__ __launch_bounds__(256) void fast9_tile_kernel(FastArgs a)
 {
-    __shared__ uint8_t img[FT_IH][FT_IW + 4];
+    __shared__ __align__(4) uint8_t img[FT_IH][FT_IW + 4];
     __shared__ int st[FT_SH][FT_SW + 1];
-    __shared__ uint64_t stage[FT_W * FT_H];
+    constexpr int FT_STAGE = 512;                      // staged candidates per tile; the rare tile with more appends the rest one by one
+    __shared__ uint64_t stage[FT_STAGE];
     __shared__ int lcnt, gbase;
     const int tid = threadIdx.x;
     const int frame = blockIdx.x % a.frames, tile = blockIdx.x / a.frames;
@@ -652,29 +653,56 @@ __global__ __launch_bounds__(256) void fast9_tile_kernel(FastArgs a)
     const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
     const int w = a.w, h = a.h;
     if (tid == 0) lcnt = 0;
-    for (int idx = tid; idx < FT_IH * FT_IW; idx += 256) {
-        const int ly = idx / FT_IW, lx = idx - ly * FT_IW, gx = x0 - 4 + lx, gy = y0 - 4 + ly;
-        img[ly][lx] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? gray[(size_t)gy * a.stride + gx] : (uint8_t)0;
+    if (((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)a.stride) & 3) == 0) {
+        // rows start on 4-byte boundaries and x0 - 4 is a multiple of 4: whole words, bytes past the image zeroed
+        for (int idx = tid; idx < FT_IH * (FT_IW / 4); idx += 256) {
+            const int ly = idx / (FT_IW / 4), lw = idx - ly * (FT_IW / 4), gx = x0 - 4 + 4 * lw, gy = y0 - 4 + ly;
+            uint32_t v = 0;
+            if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+                if (gx + 4 <= a.stride) v = *reinterpret_cast<const uint32_t *>(gray + (size_t)gy * a.stride + gx);
+                else for (int q = 0; q < 4 && gx + q < a.stride; ++q) v |= (uint32_t)gray[(size_t)gy * a.stride + gx + q] << (8 * q);
+                if (gx + 4 > w) v &= 0xffffffffu >> (8 * (gx + 4 - w));
+            }
+            *reinterpret_cast<uint32_t *>(&img[ly][4 * lw]) = v;
+        }
+    } else {
+        for (int idx = tid; idx < FT_IH * FT_IW; idx += 256) {
+            const int ly = idx / FT_IW, lx = idx - ly * FT_IW, gx = x0 - 4 + lx, gy = y0 - 4 + ly;
+            img[ly][lx] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? gray[(size_t)gy * a.stride + gx] : (uint8_t)0;
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < FT_SH * FT_SW; idx += 256) {
-        const int ly = idx / FT_SW, lx = idx - ly * FT_SW, px = x0 - 1 + lx, py = y0 - 1 + ly;
+    // strengths of the tile and its 1-pixel ring (FT_SW x FT_SH): 64 columns x 4 rows per pass, then the two
+    // remaining columns
+    auto strength_at = [&](int lx, int ly) {
+        const int px = x0 - 1 + lx, py = y0 - 1 + ly;
         int s = 0;
         if (px >= 3 && py >= 3 && px < w - 3 && py < h - 3) {
-            const int cy = ly + 3, cx = lx + 3, v = img[cy][cx];
-            int d[16];
-            d[0] = img[cy + 3][cx] - v;      d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
-            d[4] = img[cy][cx + 3] - v;      d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
-            d[8] = img[cy - 3][cx] - v;      d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
-            d[12] = img[cy][cx - 3] - v;     d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
-            s = fast9_strength(d);
-            if (s <= a.threshold) s = 0;
+            const int cy = ly + 3, cx = lx + 3, v = img[cy][cx], t = a.threshold;
+            // an arc of 9 of the 16 ring pixels contains one pixel of every opposite pair: the vertical pair
+            // rejects most pixels (whole wavefronts in flat regions stop here), the horizontal one most others
+            const int q0 = img[cy + 3][cx] - v, q8 = img[cy - 3][cx] - v;
+            const bool up = max(q0, q8) > t, dn = min(q0, q8) < -t;
+            if (up || dn) {
+                const int q4 = img[cy][cx + 3] - v, q12 = img[cy][cx - 3] - v;
+                if ((up && max(q4, q12) > t) || (dn && min(q4, q12) < -t)) {
+                    int d[16];
+                    d[0] = q0;                        d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
+                    d[4] = q4;                        d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
+                    d[8] = q8;                        d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
+                    d[12] = q12;                      d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
+                    s = fast9_strength(d);
+                    if (s <= t) s = 0;
+                }
+            }
         }
         st[ly][lx] = s;
-    }
+    };
+    for (int ly = tid >> 6; ly < FT_SH; ly += 4) strength_at(tid & 63, ly);
+    if (tid < 2 * FT_SH) strength_at(FT_W + (tid & 1), tid >> 1);
     __syncthreads();
-    for (int idx = tid; idx < FT_W * FT_H; idx += 256) {
-        const int ly = idx / FT_W, lx = idx - ly * FT_W, px = x0 + lx, py = y0 + ly;
+    for (int ly = tid >> 6; ly < FT_H; ly += 4) {
+        const int lx = tid & 63, px = x0 + lx, py = y0 + ly;
         if (px >= w || py >= h) continue;
         const int s = st[ly + 1][lx + 1];
         if (s == 0) continue;
@@ -684,13 +712,22 @@ __global__ __launch_bounds__(256) void fast9_tile_kernel(FastArgs a)
                                max(max(st[ly + 1][lx + 2], st[ly + 2][lx]), max(st[ly + 2][lx + 1], st[ly + 2][lx + 2])));
             keep = s > nb;
         }
-        if (keep) stage[atomicAdd(&lcnt, 1)] = make_key((float)(s - 1), px, py);
+        if (keep) {
+            const uint64_t key = make_key((float)(s - 1), px, py);
+            const int slot = atomicAdd(&lcnt, 1);
+            if (slot < FT_STAGE) stage[slot] = key;
+            else {
+                const int gslot = atomicAdd(a.cand_count + (size_t)frame * 2, 1);
+                if (gslot < CAND_CAP) a.cand[(size_t)frame * 2 * CAND_CAP + gslot] = key;
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0) gbase = lcnt ? atomicAdd(a.cand_count + (size_t)frame * 2, lcnt) : 0;
+    const int nstaged = min(lcnt, FT_STAGE);
+    if (tid == 0) gbase = nstaged ? atomicAdd(a.cand_count + (size_t)frame * 2, nstaged) : 0;
     __syncthreads();
     uint64_t *dst = a.cand + (size_t)frame * 2 * CAND_CAP;
-    for (int i = tid; i < lcnt; i += 256)
+    for (int i = tid; i < nstaged; i += 256)
         if (gbase + i < CAND_CAP) dst[gbase + i] = stage[i];
 }
 
