@@ -18,7 +18,7 @@
 // The reference passes Eigen objects; Eigen is not a dependency here, so the
 // mirror uses two tiny column-major value types (Vector, Matrix) with the same
 // resize / data / rows / cols surface.  With Eigen available the functors accept
-// Eigen::VectorXd / MatrixXd unchanged (see INTEGRATION.md): only .data(),
+// Eigen::VectorXd / MatrixXd unchanged: only .data(),
 // .rows(), .cols(), .size() and .resize() are used.
 //
 // Contract violations that the reference asserts on throw std::runtime_error
