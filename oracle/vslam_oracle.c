@@ -588,7 +588,7 @@ void orc_point_loglik_analytic(const double *x, int n, const double *y, const ui
     if (H) memset(H, 0, sizeof(double) * (size_t)n * n);
     double val = 0.0;
     for (int l = 0; l < L; ++l) {
-        double v, g9[9], H81[81];
+        double v = 0.0, g9[9], H81[81];
         int idx[9];
         for (int a = 0; a < 6; ++a) idx[a] = 6 + a;
         for (int a = 0; a < 3; ++a) idx[6 + a] = 12 + 3 * l + a;
