@@ -39,7 +39,7 @@ static void mat3_tvec(const double *A, const double *v, double *out) /* out = A^
     for (int c = 0; c < 3; ++c)
         out[c] = A[0 + 3 * c] * v[0] + A[1 + 3 * c] * v[1] + A[2 + 3 * c] * v[2];
 }
-static void mat3_vec(const double *A, const double *v, double *out) /* out = A v */
+static void __attribute__((unused)) mat3_vec(const double *A, const double *v, double *out) /* out = A v */
 {
     for (int r = 0; r < 3; ++r)
         out[r] = A[r + 0] * v[0] + A[r + 3] * v[1] + A[r + 6] * v[2];
@@ -416,7 +416,7 @@ void orc_point_loglik_dual_sparse(const double *x, int n, const double *y, const
         for (int a = 0; a < 3; ++a) idx[6 + a] = 12 + 3 * l + a;
         d2 z[9];
         for (int a = 0; a < 9; ++a) z[a] = d2k(x[idx[a]]);
-        d2 term;
+        d2 term = d2k(0.0);
         int flag = d2_landmark_term(z, z + 6, y + 2 * l, cam, &k, sigma, &term);
         if (code) code[l] = flag;
         if (!visible[l] || flag != 0) continue;
