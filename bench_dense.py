@@ -97,6 +97,27 @@ def run_dense_leg(ctx, dev, stream):
     torch.cuda.synchronize()
     mms = e0.elapsed_time(e1) / 10
     frame["match_hamming_64_frames_ms"] = mms
+    # selection of new landmarks: 64 frames x 10,000 sorted keypoints against 100 map landmarks, room for 50 new ones
+    Ks, Ls = 10000, 100
+    rs = np.random.default_rng(8)
+    fz = np.zeros((Bm, Ks, 3), dtype=np.int32)
+    fz[:, :, 0] = rs.integers(0, 1920, (Bm, Ks))
+    fz[:, :, 1] = rs.integers(0, 1080, (Bm, Ks))
+    fz[:, :, 2] = np.sort(rs.uniform(1e-4, 1e-2, (Bm, Ks)).astype(np.float32), axis=1)[:, ::-1].copy().view(np.int32)
+    sel_feats = torch.tensor(fz, device=dev)
+    sel_lm = torch.tensor(np.stack([rs.uniform(0, 1920, (Bm, Ls)), rs.uniform(0, 1080, (Bm, Ls))], axis=2).astype(np.float32), device=dev)
+    sel_out = torch.zeros((Bm, 64), dtype=torch.int32, device=dev)
+    sel_cnt = torch.zeros(Bm, dtype=torch.int32, device=dev)
+    sp = api.select_params(max_new=50)
+    api.select_new_landmarks_batch_dev(ctx, sel_feats, None, Ks, sel_lm, None, Ls, sp, sel_out, sel_cnt)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(10):
+        api.select_new_landmarks_batch_dev(ctx, sel_feats, None, Ks, sel_lm, None, Ls, sp, sel_out, sel_cnt)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    frame["select_new_landmarks_64_frames_ms"] = e0.elapsed_time(e1) / 10
+    frame["select_new_landmarks_mean_taken"] = float(sel_cnt.float().mean().item())
     frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
     # a bank of independent filters on one GPU: one context (stream + workspace) per host thread

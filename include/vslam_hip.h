@@ -302,6 +302,30 @@ vslam_status vslam_corner_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, 
                                            const vslam_corner_params *params, int detector,
                                            vslam_feature *out, int cap, int32_t *count);
 
+/* ---- selection of new landmarks ----
+ * The loop of src/SLAM.cpp:449-472 over the features sorted by score (src/SLAM.cpp:457): feature i becomes a
+ * landmark iff fewer than max_new were taken so far, feats[i].score > feature_thresh, width_thresh <= x <=
+ * image_width - width_thresh, height_thresh <= y <= image_height - height_thresh and pixelDistance
+ * (src/SLAM.cpp:746-760) finds no landmark -- of the map (landmark_xy: L pairs x, y) or taken earlier in this
+ * loop -- closer than pixel_distance_thresh.  selected[0..min(*count, cap)) are the indices taken, in order;
+ * max_new = max_landmarks - landmarks in the map, at most 1024. */
+typedef struct {
+    double feature_thresh, width_thresh, height_thresh, pixel_distance_thresh;
+    int32_t image_width, image_height, max_new, reserved;
+} vslam_select_params;
+/* pixelDistance(landmarks, keypoint, thresh), src/SLAM.cpp:746-760 (host function; its loop index, which the
+ * reference leaves uninitialised, starts at 0): 1 iff some landmark pixel is closer than thresh. */
+int vslam_pixel_distance(const float *landmark_xy, int L, float x, float y, double thresh);
+vslam_status vslam_select_new_landmarks(vslam_ctx *ctx, const vslam_feature *feats, int K, const float *landmark_xy, int L,
+                                        const vslam_select_params *params, int32_t *selected, int cap, int32_t *count);
+/* Device-pointer batch, one frame per workgroup: frame b reads feats + b*stride_feats (k_each[b] of them if
+ * k_each is given, else K; negative counts read as 0), landmark_xy + b*stride_lm (floats; l_each[b] pairs if
+ * given, else L) and writes selected + b*cap, count[b].  Queued, not synchronised. */
+vslam_status vslam_select_new_landmarks_batch_dev(vslam_ctx *ctx, const vslam_feature *feats, size_t stride_feats,
+                                                  const int32_t *k_each, int K, const float *landmark_xy, size_t stride_lm,
+                                                  const int32_t *l_each, int L, const vslam_select_params *params, int batch,
+                                                  int32_t *selected, int cap, int32_t *count);
+
 /* FAST-9/16 with non-maximum suppression, the first stage of cv::ORB::detect as the reference configures
  * it (src/imagefeatures.cpp:73-87, fastThreshold 20).  OpenCV's code is not part of the reference, so the
  * contract is the published segment test with OpenCV's conventions: a pixel is a corner iff 9 contiguous

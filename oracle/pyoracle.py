@@ -328,6 +328,26 @@ def corner_detect(gray, params, which, cap=None):
     return out[:n].copy()
 
 
+def pixel_distance(landmark_xy, x, y, thresh):
+    """pixelDistance (reference src/SLAM.cpp:746-760): is any landmark pixel closer than thresh?"""
+    lm = np.ascontiguousarray(landmark_xy, dtype=np.float32).reshape(-1, 2)
+    _lib.orc_pixel_distance.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_double]
+    return bool(_lib.orc_pixel_distance(lm.ctypes.data_as(C.c_void_p), lm.shape[0], float(x), float(y), float(thresh)))
+
+
+def select_new_landmarks(feats, landmark_xy, feature_thresh, width_thresh, height_thresh, dist_thresh, image_w, image_h, max_new):
+    """The selection loop of new landmarks (reference src/SLAM.cpp:449-472): indices into feats, in order."""
+    feats = np.ascontiguousarray(feats, dtype=FEATURE_DTYPE)
+    lm = np.ascontiguousarray(landmark_xy, dtype=np.float32).reshape(-1, 2)
+    sel = np.zeros(max(max_new, 1), dtype=np.int32)
+    _lib.orc_select_new_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = _lib.orc_select_new_landmarks(feats.ctypes.data_as(C.c_void_p), feats.size, lm.ctypes.data_as(C.c_void_p), lm.shape[0],
+                                      float(feature_thresh), float(width_thresh), float(height_thresh), float(dist_thresh),
+                                      int(image_w), int(image_h), int(max_new), sel.ctypes.data_as(C.c_void_p), sel.size)
+    return sel[:min(n, sel.size)].copy()
+
+
 def fast9_strength(gray, x, y):
     gray = np.ascontiguousarray(gray, dtype=np.uint8)
     h, w = gray.shape

@@ -1450,3 +1450,49 @@ int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshol
     free(cand); free(st);
     return nout;
 }
+
+
+/* ---- caller-side selection of new landmarks, src/SLAM.cpp:449-472 with pixelDistance, src/SLAM.cpp:746-760
+ * (pinned by test/src/pixelDistance.cpp).  The loop index of pixelDistance is uninitialised in the reference
+ * (`for(int i; ...)`); it is defined as 0 here.  Arithmetic as there: cv::Point2f difference, float products and
+ * sum, float square root, comparison with the double threshold. */
+int orc_pixel_distance(const float *landmark_xy, int L, float x, float y, double thresh)
+{
+    int within = 0;
+    for (int i = 0; i < L; ++i) {
+        volatile float dx = landmark_xy[2 * i] - x, dy = landmark_xy[2 * i + 1] - y;
+        volatile float xx = dx * dx, yy = dy * dy;
+        volatile float d2 = xx + yy;
+        float dist = sqrtf(d2);
+        if ((double)dist < thresh) within = 1;
+    }
+    return within;
+}
+
+/* feats: K records sorted by score descending (src/SLAM.cpp:457).  landmark_xy: 2 x L pixel positions of the
+ * landmarks already in the map.  A feature is taken iff capacity is left, no landmark (old or just taken) is
+ * within the radius, it lies inside the margins and its score exceeds the threshold (src/SLAM.cpp:459-472).
+ * Returns the number taken; selected[] receives their indices into feats, in order. */
+int orc_select_new_landmarks(const orc_feature *feats, int K, const float *landmark_xy, int L, double feature_thresh,
+                             double width_thresh, double height_thresh, double dist_thresh, int image_w, int image_h,
+                             int max_new, int32_t *selected, int cap)
+{
+    float *lm = (float *)malloc(sizeof(float) * 2 * (size_t)(L + (max_new > 0 ? max_new : 0) + 1));
+    memcpy(lm, landmark_xy, sizeof(float) * 2 * (size_t)L);
+    int nl = L, taken = 0;
+    for (int i = 0; i < K; ++i) {
+        int room = max_new - taken;
+        float fx = (float)feats[i].x, fy = (float)feats[i].y;
+        int score_ok = (double)feats[i].score > feature_thresh;
+        int in_w = width_thresh <= (double)fx && (double)fx <= (double)image_w - width_thresh;
+        int in_h = height_thresh <= (double)fy && (double)fy <= (double)image_h - height_thresh;
+        int within = nl > 0 ? orc_pixel_distance(lm, nl, fx, fy, dist_thresh) : 0;
+        if (room > 0 && !within && in_w && in_h && score_ok) {
+            lm[2 * nl] = fx; lm[2 * nl + 1] = fy; ++nl;
+            if (taken < cap) selected[taken] = i;
+            ++taken;
+        }
+    }
+    free(lm);
+    return taken;
+}

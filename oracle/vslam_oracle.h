@@ -184,6 +184,11 @@ void orc_corner_response(const uint8_t *gray, int w, int h, int stride,
  * descending (ties: y then x ascending), at most min(cap, max_features). */
 int orc_corner_detect(const uint8_t *gray, int w, int h, int stride,
                       const orc_corner_params *p, int which, orc_feature *out, int cap);
+/* pixelDistance (src/SLAM.cpp:746-760) and the selection loop of new landmarks (src/SLAM.cpp:449-472). */
+int orc_pixel_distance(const float *landmark_xy, int L, float x, float y, double thresh);
+int orc_select_new_landmarks(const orc_feature *feats, int K, const float *landmark_xy, int L, double feature_thresh,
+                             double width_thresh, double height_thresh, double dist_thresh, int image_w, int image_h,
+                             int max_new, int32_t *selected, int cap);
 /* FAST-9/16 (first stage of cv::ORB::detect, src/imagefeatures.cpp:73-87): strength of one pixel and the detector. */
 int orc_fast9_strength(const uint8_t *gray, int w, int h, int stride, int x, int y);
 int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax, int max_features,

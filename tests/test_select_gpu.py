@@ -1,0 +1,79 @@
+"""New-landmark selection on the GPU (vslam_select_new_landmarks*, reference src/SLAM.cpp:449-472 with
+pixelDistance, :746-760) against the CPU oracle: index lists identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, K, L, spread=1.0):
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(seed)
+    feats = np.zeros(K, dtype=orc.FEATURE_DTYPE)
+    feats["x"] = rng.integers(0, int(1920 * spread), K)
+    feats["y"] = rng.integers(0, int(1080 * spread), K)
+    feats["score"] = np.sort(rng.uniform(0, 1e-3, K).astype(np.float32))[::-1]
+    lm = np.stack([rng.uniform(0, 1920, L), rng.uniform(0, 1080, L)], axis=1).astype(np.float32)
+    return feats, lm
+
+
+@pytest.mark.parametrize("seed,K,L,max_new,radius", [(0, 0, 0, 10, 150.0), (1, 1, 0, 10, 150.0), (2, 255, 3, 50, 150.0), (3, 256, 0, 50, 150.0),
+                                                    (4, 257, 40, 50, 150.0), (5, 10000, 100, 50, 150.0), (6, 10000, 0, 1000, 20.0),
+                                                    (7, 3000, 150, 0, 150.0), (8, 5000, 10, 300, 0.0), (9, 2000, 5, 40, 60.5)])
+def test_selection_matches_oracle(ctx, seed, K, L, max_new, radius):
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    feats, lm = _case(seed, K, L)
+    p = api.select_params(pixel_distance_thresh=radius, max_new=max_new)
+    want = orc.select_new_landmarks(feats, lm, 1e-4, 250, 100, radius, 1920, 1080, max_new)
+    got = api.select_new_landmarks(ctx, feats, lm, p)
+    assert got.tolist() == want.tolist()
+
+
+def test_selection_reference_scenario(ctx):
+    """Keypoints of the corner detector on a synthetic frame, the reference's scenario-2 thresholds."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    img = syn.frame(5003)
+    feats = api.corner_detect(ctx, img, api.corner_params(), api.HARRIS)
+    assert feats.size > 500
+    p = api.select_params(max_new=50)
+    got = api.select_new_landmarks(ctx, feats, np.zeros((0, 2), np.float32), p)
+    want = orc.select_new_landmarks(feats, np.zeros((0, 2)), 1e-4, 250, 100, 150, 1920, 1080, 50)
+    assert got.tolist() == want.tolist() and 5 < got.size <= 50
+    xy = np.stack([feats["x"][got], feats["y"][got]], axis=1).astype(np.float64)
+    d = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(-1)) + 1e9 * np.eye(got.size)
+    assert d.min() >= 150.0
+
+
+def test_selection_errors(ctx):
+    from visualslam_amd import api
+    feats, lm = _case(1, 10, 2)
+    with pytest.raises(api.VslamError):
+        api.select_new_landmarks(ctx, feats, lm, api.select_params(max_new=2000))
+    with pytest.raises(api.VslamError):
+        api.select_new_landmarks(ctx, feats, lm, api.select_params(pixel_distance_thresh=-1.0))
+
+
+def test_selection_batch_dev(ctx):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    B, K, L, cap = 6, 1500, 30, 64
+    dev = torch.device("cuda:0")
+    cases = [_case(50 + b, K, L) for b in range(B)]
+    k_each = np.array([K, 0, 700, K, 1, -1], dtype=np.int32)
+    l_each = np.array([L, L, 0, 7, L, L], dtype=np.int32)
+    F = np.stack([c[0] for c in cases])
+    feats = torch.tensor(F.view(np.int32).reshape(B, K, 3), device=dev)
+    lms = torch.tensor(np.stack([c[1] for c in cases]), device=dev)
+    sel = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    p = api.select_params(max_new=40)
+    api.select_new_landmarks_batch_dev(ctx, feats, torch.tensor(k_each, device=dev), K, lms, torch.tensor(l_each, device=dev), L, p, sel, cnt)
+    torch.cuda.synchronize()
+    for b in range(B):
+        kb, lb = max(int(k_each[b]), 0), int(l_each[b])
+        want = orc.select_new_landmarks(cases[b][0][:kb], cases[b][1][:lb], 1e-4, 250, 100, 150, 1920, 1080, 40)
+        n = int(cnt[b])
+        assert n == want.size and sel[b, :n].cpu().numpy().tolist() == want.tolist()

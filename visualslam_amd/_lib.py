@@ -25,6 +25,12 @@ class CornerParams(C.Structure):
                 ("harris_k", C.c_float), ("harris_thresh", C.c_float), ("shi_thresh", C.c_float)]
 
 
+class SelectParams(C.Structure):
+    _fields_ = [("feature_thresh", C.c_double), ("width_thresh", C.c_double), ("height_thresh", C.c_double),
+                ("pixel_distance_thresh", C.c_double), ("image_width", C.c_int32), ("image_height", C.c_int32),
+                ("max_new", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Feature(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("score", C.c_float)]
 
@@ -116,6 +122,8 @@ def _declare(L):
         "vslam_match_hamming_batch_dev": [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp, _i, _i, _vp, _vp],
         "vslam_corner_detect": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
         "vslam_corner_response": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _vp, _vp],
+        "vslam_select_new_landmarks": [_vp, _vp, _i, _vp, _i, C.POINTER(SelectParams), _vp, _i, _vp],
+        "vslam_select_new_landmarks_batch_dev": [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(SelectParams), _i, _vp, _i, _vp],
         "vslam_fast9_detect": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_fast9_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
@@ -131,6 +139,8 @@ def _declare(L):
     L.vslam_normcdf.argtypes = [_d]
     L.vslam_chi2inv.restype = C.c_double
     L.vslam_chi2inv.argtypes = [_d, _d]
+    L.vslam_pixel_distance.restype = C.c_int
+    L.vslam_pixel_distance.argtypes = [_vp, _i, C.c_float, C.c_float, _d]
 
 
 def check(status, ctx=None):

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, CornerParams, VslamError, check  # noqa: F401
+from ._lib import Camera, CornerParams, SelectParams, VslamError, check  # noqa: F401
 
 FEATURE_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("score", np.float32)])
 LAYOUT_COMPAT, LAYOUT_STRICT = 0, 1
@@ -323,6 +323,42 @@ def corner_detect(ctx, gray, params, detector=HARRIS, cap=None):
     cnt = np.zeros(1, dtype=np.int32)
     check(ctx._L.vslam_corner_detect(ctx.ptr, _p(gray), w, h, w, C.byref(params), detector, _p(out), cap, _p(cnt)), ctx.ptr)
     return out[:int(cnt[0])].copy()
+
+
+def select_params(feature_thresh=1e-4, width_thresh=250.0, height_thresh=100.0, pixel_distance_thresh=150.0,
+                  image_width=1920, image_height=1080, max_new=50):
+    """Defaults: the reference's scenario-2 tuning (src/SLAM.cpp:113-120)."""
+    p = SelectParams()
+    p.feature_thresh, p.width_thresh, p.height_thresh = feature_thresh, width_thresh, height_thresh
+    p.pixel_distance_thresh = pixel_distance_thresh
+    p.image_width, p.image_height, p.max_new = image_width, image_height, max_new
+    return p
+
+
+def pixel_distance(landmark_xy, x, y, thresh):
+    """pixelDistance (reference src/SLAM.cpp:746-760), host function."""
+    lm = np.ascontiguousarray(landmark_xy, dtype=np.float32).reshape(-1, 2)
+    return bool(_lib.lib().vslam_pixel_distance(_p(lm) if lm.size else None, lm.shape[0], float(x), float(y), float(thresh)))
+
+
+def select_new_landmarks(ctx, feats, landmark_xy, params, cap=None):
+    """The selection loop of new landmarks (reference src/SLAM.cpp:449-472): indices into feats, in order."""
+    feats = np.ascontiguousarray(feats, dtype=FEATURE_DTYPE)
+    lm = np.ascontiguousarray(landmark_xy, dtype=np.float32).reshape(-1, 2)
+    cap = max(int(params.max_new), 1) if cap is None else cap
+    sel = np.zeros(cap, dtype=np.int32)
+    cnt = np.zeros(1, dtype=np.int32)
+    check(ctx._L.vslam_select_new_landmarks(ctx.ptr, _p(feats) if feats.size else None, feats.size, _p(lm) if lm.size else None,
+                                            lm.shape[0], C.byref(params), _p(sel), cap, _p(cnt)), ctx.ptr)
+    return sel[:min(int(cnt[0]), cap)].copy()
+
+
+def select_new_landmarks_batch_dev(ctx, feats, k_each, K, landmark_xy, l_each, L, params, selected, count):
+    """torch tensors on the GPU: feats (B, K, 3) int32 records, k_each (B,) int32 or None, landmark_xy (B, L, 2) f32,
+    l_each (B,) int32 or None, selected (B, cap) int32, count (B,) int32."""
+    B, cap = selected.shape
+    check(ctx._L.vslam_select_new_landmarks_batch_dev(ctx.ptr, _tpc(feats), K, _tpc(k_each), K, _tpc(landmark_xy), 2 * L, _tpc(l_each), L,
+                                                      C.byref(params), B, _tpc(selected), cap, _tpc(count)), ctx.ptr)
 
 
 def fast9_detect(ctx, gray, threshold=20, nonmax=True, max_features=16384, cap=None, stride=None):
