@@ -306,6 +306,24 @@ static void test_time_update()
 }
 
 // removeBadLandmarks (src/SLAM.cpp:796-820) and the descriptor matcher (src/SLAM.cpp:355).
+// test/src/pixelDistance.cpp: landmarks at (0,0) and (100,0)
+static void test_pixel_distance_and_selection()
+{
+    std::vector<KeyPoint> lms(2);
+    lms[1].x = 100.0f;
+    KeyPoint kp;
+    CHECK_TRUE(pixelDistance(lms, kp, 10.0));                 // :9-39
+    CHECK_TRUE(pixelDistance(lms, kp, 200.0));                // :41-71
+    kp.x = 500.0f; kp.y = 500.0f;
+    CHECK_TRUE(!pixelDistance(lms, kp, 200.0));               // :73-105
+    // the loop of src/SLAM.cpp:449-472 on five sorted keypoints, empty map, the reference's thresholds
+    std::vector<vslam_feature> f = {{300, 300, 5.0f}, {310, 305, 4.0f}, {900, 500, 3.0f}, {960, 540, 2.0f}, {1700, 900, 1.0f}};
+    std::vector<int32_t> sel = selectNewLandmarks(f, {}, 1e-4, 250.0, 100.0, 150.0, 1920, 1080, 10);
+    CHECK_TRUE(sel.size() == 2 && sel[0] == 0 && sel[1] == 2);   // 1 and 3 are within 150 px of a taken one, 4 is outside the margin
+    sel = selectNewLandmarks(f, {}, 1e-4, 250.0, 100.0, 150.0, 1920, 1080, 1);
+    CHECK_TRUE(sel.size() == 1 && sel[0] == 0);
+}
+
 static void test_landmark_bookkeeping()
 {
     const int n = 21;
@@ -370,6 +388,7 @@ int main(int argc, char **argv)
         test_data_association(argv[1]);
         test_time_update();
         test_landmark_bookkeeping();
+        test_pixel_distance_and_selection();
         // Contract violations surface as exceptions carrying the library's message, not aborts.
         bool threw = false;
         try {

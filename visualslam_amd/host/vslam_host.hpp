@@ -25,6 +25,7 @@
 // carrying the library's message.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <initializer_list>
@@ -298,6 +299,32 @@ void removeBadLandmarks(Vec &mup, Mat &Sp, std::vector<LandmarkT> &landmarks, in
 
 // cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches), src/SLAM.cpp:222,355, on row-major
 // descriptor arrays: the train index (and distance) of the nearest descriptor for every query row.
+// ---- selection of new landmarks (src/SLAM.cpp:449-472) and pixelDistance (src/SLAM.cpp:746-760) ----
+struct KeyPoint { float x = 0.0f, y = 0.0f, response = 0.0f; };   // the fields of cv::KeyPoint the loop reads (pt.x, pt.y, response)
+inline bool pixelDistance(const std::vector<KeyPoint> &landmark_keypoints, const KeyPoint &keypoint, double pixel_distance_thresh)
+{
+    std::vector<float> lm(2 * landmark_keypoints.size());
+    for (size_t i = 0; i < landmark_keypoints.size(); ++i) { lm[2 * i] = landmark_keypoints[i].x; lm[2 * i + 1] = landmark_keypoints[i].y; }
+    return vslam_pixel_distance(lm.data(), (int)landmark_keypoints.size(), keypoint.x, keypoint.y, pixel_distance_thresh) != 0;
+}
+// sorted: keypoints sorted by response, descending (sortByScore, src/imagefeatures.cpp:20-22) with integer pixel
+// positions, as the detectors of this library return them.  Returns the indices that become landmarks, in order.
+inline std::vector<int32_t> selectNewLandmarks(const std::vector<vslam_feature> &sorted, const std::vector<KeyPoint> &landmark_keypoints,
+                                               double feature_thresh, double initial_width_thresh, double initial_height_thresh,
+                                               double initial_pixel_distance_thresh, int image_width, int image_height, int max_new_landmarks)
+{
+    std::vector<float> lm(2 * landmark_keypoints.size());
+    for (size_t i = 0; i < landmark_keypoints.size(); ++i) { lm[2 * i] = landmark_keypoints[i].x; lm[2 * i + 1] = landmark_keypoints[i].y; }
+    vslam_select_params sp{feature_thresh, initial_width_thresh, initial_height_thresh, initial_pixel_distance_thresh,
+                           image_width, image_height, max_new_landmarks, 0};
+    std::vector<int32_t> sel((size_t)(max_new_landmarks > 0 ? max_new_landmarks : 1));
+    int32_t count = 0;
+    check(vslam_select_new_landmarks(context(), sorted.empty() ? nullptr : sorted.data(), (int)sorted.size(), lm.empty() ? nullptr : lm.data(),
+                                     (int)landmark_keypoints.size(), &sp, sel.data(), (int)sel.size(), &count));
+    sel.resize((size_t)std::min<int32_t>(count, (int32_t)sel.size()));
+    return sel;
+}
+
 struct Match { int queryIdx, trainIdx; float distance; };       // the fields of cv::DMatch the caller reads
 inline void matchHamming(const uint8_t *query, int nq, const uint8_t *train, int nt, int desc_bytes, std::vector<Match> &matches)
 {
