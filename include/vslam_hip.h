@@ -326,6 +326,26 @@ vslam_status vslam_select_new_landmarks_batch_dev(vslam_ctx *ctx, const vslam_fe
                                                   const int32_t *l_each, int L, const vslam_select_params *params, int batch,
                                                   int32_t *selected, int cap, int32_t *count);
 
+/* ---- initialisation of new landmarks ----
+ * generateOpticalRay(param, pixel, p), src/SLAM.cpp:876-903 (host function): ray[3] = ray_length * K^-1 [u' v' 1]^T
+ * with (u', v') the pixel freed of lens distortion.  The reference obtains (u', v') from
+ * cv::undistortPoints(pixel, K, dist, I, [K | 0]); OpenCV is not part of the reference, so the contract is that
+ * routine's documented iteration (five fixed-point steps, coefficients cam->d[0..11] in OpenCV's order whatever
+ * the flag, pixel and result stored as float).  Returns 0, or 1 on a null pointer or non-finite constants. */
+int vslam_optical_ray(const vslam_camera *cam, double u, double v, double ray_length, double *ray);
+/* initializeNewLandmark(...), src/SLAM.cpp:905-941, for M keypoints at once (the reference appends them one
+ * per call from the same predicted pose, which gives the same state): mu_out (n + 3M) = [mu; r_1 .. r_M] with
+ * r_t = mu[6..8] + Rnc(mu[9..11]) * ray(pixels[2t], pixels[2t+1]) (src/SLAM.cpp:918-929), S_out
+ * ((n+3M) x (n+3M), ldSout) = [S 0; 0 kappa I] (src/SLAM.cpp:908-915).  pixels: M pairs u, v. */
+vslam_status vslam_initialize_landmarks(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n, int ldS,
+                                        const double *pixels, int M, double ray_length, double kappa,
+                                        double *mu_out, double *S_out, int ldSout);
+/* The same on device-resident state: every pointer but cam is a device pointer, the outputs must not overlap
+ * the inputs.  Queued on the context's stream, not synchronised. */
+vslam_status vslam_initialize_landmarks_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n, int ldS,
+                                            const double *pixels, int M, double ray_length, double kappa,
+                                            double *mu_out, double *S_out, int ldSout);
+
 /* FAST-9/16 with non-maximum suppression, the first stage of cv::ORB::detect as the reference configures
  * it (src/imagefeatures.cpp:73-87, fastThreshold 20).  OpenCV's code is not part of the reference, so the
  * contract is the published segment test with OpenCV's conventions: a pixel is a corner iff 9 contiguous

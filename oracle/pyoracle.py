@@ -328,6 +328,28 @@ def corner_detect(gray, params, which, cap=None):
     return out[:n].copy()
 
 
+def optical_ray(cam, u, v, length=8.0):
+    """generateOpticalRay (reference src/SLAM.cpp:876-903): ray of the pixel in camera coordinates, times length."""
+    r = np.zeros(3)
+    _lib.orc_optical_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    _lib.orc_optical_ray.restype = None
+    _lib.orc_optical_ray(C.byref(cam), float(u), float(v), float(length), r.ctypes.data_as(C.c_void_p))
+    return r
+
+
+def initialize_landmark(mu, S, cam, u, v, length=8.0, kappa=0.5):
+    """initializeNewLandmark (reference src/SLAM.cpp:905-941): (mu, S) with the landmark of pixel (u, v) appended."""
+    mu, S = _f64(mu), _F(S)
+    n = mu.size
+    mo, So = np.zeros(n + 3), np.zeros((n + 3, n + 3), order="F")
+    _lib.orc_initialize_landmark.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, C.c_void_p, C.c_void_p]
+    _lib.orc_initialize_landmark.restype = None
+    _lib.orc_initialize_landmark(mu.ctypes.data_as(C.c_void_p), S.ctypes.data_as(C.c_void_p), n, n, C.byref(cam), float(u), float(v),
+                                 float(length), float(kappa), mo.ctypes.data_as(C.c_void_p), So.ctypes.data_as(C.c_void_p))
+    return mo, So
+
+
 def pixel_distance(landmark_xy, x, y, thresh):
     """pixelDistance (reference src/SLAM.cpp:746-760): is any landmark pixel closer than thresh?"""
     lm = np.ascontiguousarray(landmark_xy, dtype=np.float32).reshape(-1, 2)

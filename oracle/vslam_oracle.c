@@ -1496,3 +1496,61 @@ int orc_select_new_landmarks(const orc_feature *feats, int K, const float *landm
     free(lm);
     return taken;
 }
+
+
+/* ---- initialisation of a new landmark, src/SLAM.cpp:905-941 with generateOpticalRay, src/SLAM.cpp:876-903.
+ * generateOpticalRay calls cv::undistortPoints(pixel, K, distCoeffs, R = I, P = [K | 0]); OpenCV is not in this
+ * build, so its documented iteration is restated (unpinned): normalise with K, five fixed-point steps
+ *   x <- (x0 - dx(x, y)) * icdist(x, y),  icdist = (1 + k4 r2 + k5 r2^2 + k6 r2^3) / (1 + k1 r2 + k2 r2^2 + k3 r2^3),
+ *   dx = 2 p1 x y + p2 (r2 + 2 x^2) + s1 r2 + s2 r2^2,  dy = p1 (r2 + 2 y^2) + 2 p2 x y + s3 r2 + s4 r2^2
+ * with the coefficients in OpenCV's order (whatever the flag says), the result back to pixels with P and
+ * stored as cv::Point2f (float).  The ray is K^-1 [u v 1]^T times the ray length.
+ * gcc 11.4 -O3 pairs the x and y updates of the loop into SSE lanes and the result then differs from the
+ * scalar evaluation (and from clang's, and from -O2) in the seventh digit: pairing is switched off here. */
+__attribute__((optimize("no-tree-slp-vectorize")))
+void orc_undistort_point(const orc_camera *cam, double u, double v, float *out_uv)
+{
+    const double *d = cam->d;
+    const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4], k4 = d[5], k5 = d[6], k6 = d[7];
+    const double s1 = d[8], s2 = d[9], s3 = d[10], s4 = d[11];
+    /* the reference passes the pixel through a cv::Point2f */
+    double x0 = ((double)(float)u - cam->cx) / cam->fx, y0 = ((double)(float)v - cam->cy) / cam->fy;
+    double x = x0, y = y0;
+    for (int it = 0; it < 5; ++it) {
+        double r2 = x * x + y * y;
+        double icdist = (1 + ((k6 * r2 + k5) * r2 + k4) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + s1 * r2 + s2 * r2 * r2;
+        double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + s3 * r2 + s4 * r2 * r2;
+        x = (x0 - dx) * icdist;
+        y = (y0 - dy) * icdist;
+    }
+    out_uv[0] = (float)(x * cam->fx + cam->cx);
+    out_uv[1] = (float)(y * cam->fy + cam->cy);
+}
+
+void orc_optical_ray(const orc_camera *cam, double u, double v, double length, double *r)
+{
+    float uv[2];
+    orc_undistort_point(cam, u, v, uv);
+    /* K^-1 [u v 1]^T for K = [fx 0 cx; 0 fy cy; 0 0 1] */
+    r[0] = length * (((double)uv[0] - cam->cx) / cam->fx);
+    r[1] = length * (((double)uv[1] - cam->cy) / cam->fy);
+    r[2] = length;
+}
+
+/* mu_out (n+3), S_out ((n+3) x (n+3), ld n+3): state and factor with the landmark appended (src/SLAM.cpp:906-929). */
+void orc_initialize_landmark(const double *mu, const double *S, int n, int ldS, const orc_camera *cam, double u, double v,
+                             double length, double kappa, double *mu_out, double *S_out)
+{
+    int m = n + 3;
+    memset(S_out, 0, sizeof(double) * (size_t)m * m);
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) S_out[r + (size_t)m * c] = S[r + (size_t)ldS * c];
+    for (int k = 0; k < 3; ++k) S_out[(n + k) + (size_t)m * (n + k)] = kappa;
+    memcpy(mu_out, mu, sizeof(double) * (size_t)n);
+    double ray[3], R[9];
+    orc_optical_ray(cam, u, v, length, ray);
+    orc_rpy2rot(mu + 9, R);
+    for (int i = 0; i < 3; ++i)
+        mu_out[n + i] = mu[6 + i] + (R[i + 3 * 0] * ray[0] + R[i + 3 * 1] * ray[1] + R[i + 3 * 2] * ray[2]);
+}

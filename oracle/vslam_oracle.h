@@ -184,6 +184,11 @@ void orc_corner_response(const uint8_t *gray, int w, int h, int stride,
  * descending (ties: y then x ascending), at most min(cap, max_features). */
 int orc_corner_detect(const uint8_t *gray, int w, int h, int stride,
                       const orc_corner_params *p, int which, orc_feature *out, int cap);
+/* generateOpticalRay (src/SLAM.cpp:876-903) and initializeNewLandmark (src/SLAM.cpp:905-941). */
+void orc_undistort_point(const orc_camera *cam, double u, double v, float *out_uv);
+void orc_optical_ray(const orc_camera *cam, double u, double v, double length, double *r);
+void orc_initialize_landmark(const double *mu, const double *S, int n, int ldS, const orc_camera *cam, double u, double v,
+                             double length, double kappa, double *mu_out, double *S_out);
 /* pixelDistance (src/SLAM.cpp:746-760) and the selection loop of new landmarks (src/SLAM.cpp:449-472). */
 int orc_pixel_distance(const float *landmark_xy, int L, float x, float y, double thresh);
 int orc_select_new_landmarks(const orc_feature *feats, int K, const float *landmark_xy, int L, double feature_thresh,

@@ -324,6 +324,41 @@ static void test_pixel_distance_and_selection()
     CHECK_TRUE(sel.size() == 1 && sel[0] == 0);
 }
 
+// initializeNewLandmark / generateOpticalRay (src/SLAM.cpp:876-941): both states grow, the new landmarks are seen at
+// their keypoints.
+static void test_landmark_initialisation(const std::string &xml)
+{
+    Scene sc(xml, 2, 21);
+    const int n = sc.mu.rows();
+    Vector mup = sc.mu, muEKF = sc.mu;
+    Matrix Sp = sc.S, SEKF = sc.S;
+    std::vector<KeyPoint> kps(3);
+    kps[0].x = 400.0f; kps[0].y = 300.0f; kps[1].x = 1500.25f; kps[1].y = 800.5f; kps[2].x = 960.0f; kps[2].y = 540.0f;
+    initializeNewLandmarks(mup, Sp, muEKF, SEKF, kps, sc.param.camera_param, 8.0, 0.5);
+    CHECK_TRUE(mup.rows() == n + 9 && muEKF.rows() == n + 9 && Sp.rows() == n + 9 && Sp.cols() == n + 9 && SEKF.rows() == n + 9);
+    for (int i = 0; i < n; ++i) {
+        CHECK_NEAR(mup(i), sc.mu(i), 0.0);
+        CHECK_NEAR(muEKF(i), sc.mu(i), 0.0);
+        for (int j = 0; j < n; ++j) CHECK_NEAR(Sp(i, j), sc.S(i, j), 0.0);
+    }
+    for (int i = n; i < n + 9; ++i) {
+        CHECK_NEAR(muEKF(i), 0.0, 0.0);
+        for (int j = 0; j < n + 9; ++j) {
+            CHECK_NEAR(Sp(i, j), i == j ? 0.5 : 0.0, 0.0);
+            CHECK_NEAR(SEKF(j, i), i == j ? 0.5 : 0.0, 0.0);
+        }
+    }
+    MeasurementPointLandmarkSingle hs;
+    Vector y;
+    for (int t = 0; t < 3; ++t) {
+        CHECK_TRUE(hs(2 + t, mup, sc.param.camera_param, y) == 0);
+        CHECK_NEAR(y(0), kps[(size_t)t].x, 0.01);
+        CHECK_NEAR(y(1), kps[(size_t)t].y, 0.01);
+    }
+    Vector ray = generateOpticalRay(sc.param.camera_param, 960.0, 540.0, 3.0);
+    CHECK_NEAR(ray(2), 3.0, 0.0);
+}
+
 static void test_landmark_bookkeeping()
 {
     const int n = 21;
@@ -389,6 +424,7 @@ int main(int argc, char **argv)
         test_time_update();
         test_landmark_bookkeeping();
         test_pixel_distance_and_selection();
+        test_landmark_initialisation(argv[1]);
         // Contract violations surface as exceptions carrying the library's message, not aborts.
         bool threw = false;
         try {

@@ -1,0 +1,102 @@
+"""Initialisation of new landmarks on the GPU (reference src/SLAM.cpp:905-941) against the oracle: host entry
+point, device-resident entry point, M landmarks at once against M single appends.  fp64, 1e-12 relative
+(the arithmetic is a few dozen operations; the float roundings of the pixel are reproduced exactly)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _state(L, seed):
+    rng = np.random.default_rng(seed)
+    n = 12 + 3 * L
+    mu = rng.normal(size=n)
+    mu[9:12] *= 0.3
+    S = np.asfortranarray(np.triu(rng.normal(size=(n, n))))
+    return mu, S
+
+
+def _oracle_append(mu, S, cam, px, length, kappa):
+    for u, v in px:                                   # the reference appends one landmark per call
+        mu, S = orc.initialize_landmark(mu, S, cam, u, v, length, kappa)
+    return mu, S
+
+
+@pytest.mark.parametrize("L,M", [(0, 1), (1, 1), (5, 3), (150, 50), (40, 300)])
+def test_host_entry_equals_oracle(ctx, gcam, ocam, L, M):
+    from visualslam_amd import api
+    mu, S = _state(L, 10 + L)
+    rng = np.random.default_rng(M)
+    px = np.stack([rng.uniform(250, 1670, M), rng.uniform(100, 980, M)], axis=1)
+    mo, So = api.initialize_landmarks(ctx, gcam, mu, S, px, 8.0, 0.5)
+    wm, wS = _oracle_append(mu, S, ocam, px, 8.0, 0.5)
+    np.testing.assert_array_equal(mo[:mu.size], mu)
+    np.testing.assert_allclose(mo, wm, rtol=TOL, atol=TOL)
+    np.testing.assert_array_equal(So, wS)             # copies, zeros and kappa: exact
+
+
+def test_scenario_three_constants_and_leading_dimension(ctx, gcam, ocam):
+    from visualslam_amd import api
+    import ctypes as C
+    mu, S = _state(3, 2)
+    n, ld = mu.size, mu.size + 5
+    Sp = np.zeros((ld, n), order="F")
+    Sp[:n] = S
+    Sp[n:] = 7.0                                      # padding rows must not be read
+    px = np.array([[1000.5, 300.25]])
+    m, ldo = n + 3, n + 3 + 4
+    mo, So = np.zeros(m), np.full((ldo, m), -1.0, order="F")
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    api.check(ctx._L.vslam_initialize_landmarks(ctx.ptr, C.byref(gcam), p(mu), p(Sp), n, ld, p(px), 1, 3.0, 0.1, p(mo), p(So), ldo), ctx.ptr)
+    wm, wS = orc.initialize_landmark(mu, S, ocam, 1000.5, 300.25, 3.0, 0.1)
+    np.testing.assert_allclose(mo, wm, rtol=TOL, atol=TOL)
+    np.testing.assert_array_equal(So[:m], wS)
+    np.testing.assert_array_equal(So[m:], -1.0)       # padding rows of the output stay untouched
+
+
+def test_device_resident_entry(ctx, gcam, ocam):
+    import torch
+    from visualslam_amd import api
+    mu, S = _state(100, 4)
+    n, M = mu.size, 64
+    rng = np.random.default_rng(9)
+    px = np.stack([rng.uniform(250, 1670, M), rng.uniform(100, 980, M)], axis=1)
+    dev = torch.device("cuda:0")
+    dmu = torch.from_numpy(mu).to(dev)
+    dS = torch.from_numpy(np.ascontiguousarray(S.T)).to(dev)          # row-major of S^T = column-major of S
+    dpx = torch.from_numpy(px).to(dev)
+    m = n + 3 * M
+    dmo = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+    dSo = torch.full((m, m), float("nan"), dtype=torch.float64, device=dev)
+    api.initialize_landmarks_dev(ctx, gcam, dmu, dS, dpx, dmo, dSo, 8.0, 0.5)
+    ctx.synchronize()
+    wm, wS = _oracle_append(mu, S, ocam, px, 8.0, 0.5)
+    np.testing.assert_allclose(dmo.cpu().numpy(), wm, rtol=TOL, atol=TOL)
+    np.testing.assert_array_equal(dSo.cpu().numpy().T, wS)
+
+
+def test_new_landmarks_are_seen_at_their_keypoints(ctx, gcam):
+    """Property at the size of a full frame's intake: every initialised landmark projects back onto its keypoint."""
+    from visualslam_amd import api
+    mu, S = _state(0, 1)
+    rng = np.random.default_rng(3)
+    M = 1024
+    px = np.stack([rng.uniform(250, 1670, M), rng.uniform(100, 980, M)], axis=1)
+    mo, _ = api.initialize_landmarks(ctx, gcam, mu, S, px, 8.0, 0.5)
+    pix, code = api.project(ctx, gcam, mo)
+    assert not code.any()
+    assert np.max(np.abs(pix.reshape(M, 2) - px)) < 0.01
+
+
+def test_argument_errors(ctx, gcam):
+    from visualslam_amd import api
+    mu, S = _state(2, 1)
+    with pytest.raises(api.VslamError):
+        api.initialize_landmarks(ctx, gcam, mu[:-1], S[:-1, :-1], [[500.0, 500.0]])       # n is not 12 + 3L
+    with pytest.raises(api.VslamError):
+        api.initialize_landmarks(ctx, gcam, mu, S, np.zeros((0, 2)))                      # nothing to append
+    with pytest.raises(api.VslamError):
+        api.initialize_landmarks(ctx, gcam, mu, S, [[500.0, 500.0]], kappa=float("inf"))

@@ -124,6 +124,8 @@ def _declare(L):
         "vslam_corner_response": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _vp, _vp],
         "vslam_select_new_landmarks": [_vp, _vp, _i, _vp, _i, C.POINTER(SelectParams), _vp, _i, _vp],
         "vslam_select_new_landmarks_batch_dev": [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(SelectParams), _i, _vp, _i, _vp],
+        "vslam_initialize_landmarks": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _i],
+        "vslam_initialize_landmarks_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _i],
         "vslam_fast9_detect": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_fast9_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
@@ -141,6 +143,8 @@ def _declare(L):
     L.vslam_chi2inv.argtypes = [_d, _d]
     L.vslam_pixel_distance.restype = C.c_int
     L.vslam_pixel_distance.argtypes = [_vp, _i, C.c_float, C.c_float, _d]
+    L.vslam_optical_ray.restype = C.c_int
+    L.vslam_optical_ray.argtypes = [C.POINTER(Camera), _d, _d, _d, _vp]
 
 
 def check(status, ctx=None):

@@ -361,6 +361,36 @@ def select_new_landmarks_batch_dev(ctx, feats, k_each, K, landmark_xy, l_each, L
                                                       C.byref(params), B, _tpc(selected), cap, _tpc(count)), ctx.ptr)
 
 
+def optical_ray(cam, u, v, ray_length=8.0):
+    """generateOpticalRay (reference src/SLAM.cpp:876-903), host function: ray_length * K^-1 [u' v' 1]^T."""
+    r = np.zeros(3)
+    if _lib.lib().vslam_optical_ray(C.byref(cam), float(u), float(v), float(ray_length), _p(r)) != 0:
+        raise _lib.VslamError("libvslam_hip: optical_ray: camera constants or ray length are not usable")
+    return r
+
+
+def initialize_landmarks(ctx, cam, mu, S, pixels, ray_length=8.0, kappa=0.5):
+    """initializeNewLandmark (reference src/SLAM.cpp:905-941) for the keypoints pixels (M, 2): (mu, S) grown by 3M states.
+    Defaults: optical_ray_length and kappa of the reference's scenario 2 (src/SLAM.cpp:122-123)."""
+    mu, S = _f64(mu), _F(S)
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n, M = mu.size, px.shape[0]
+    m = n + 3 * M
+    mo, So = np.zeros(m), np.zeros((m, m), order="F")
+    check(ctx._L.vslam_initialize_landmarks(ctx.ptr, C.byref(cam), _p(mu), _p(S), n, S.shape[0], _p(px), M, float(ray_length), float(kappa),
+                                            _p(mo), _p(So), m), ctx.ptr)
+    return mo, So
+
+
+def initialize_landmarks_dev(ctx, cam, mu, S, pixels, mu_out, S_out, ray_length=8.0, kappa=0.5):
+    """torch tensors on the GPU: mu (n,), S (n x n, column-major: element (r, c) at c * n + r), pixels (M, 2) f64,
+    mu_out (n + 3M,), S_out ((n + 3M) x (n + 3M), column-major)."""
+    n, M = mu.numel(), pixels.shape[0]
+    m = n + 3 * M
+    check(ctx._L.vslam_initialize_landmarks_dev(ctx.ptr, C.byref(cam), _tpc(mu), _tpc(S), n, n, _tpc(pixels), M, float(ray_length),
+                                                float(kappa), _tpc(mu_out), _tpc(S_out), m), ctx.ptr)
+
+
 def fast9_detect(ctx, gray, threshold=20, nonmax=True, max_features=16384, cap=None, stride=None):
     """FAST-9/16 keypoints (first stage of cv::ORB::detect, reference src/imagefeatures.cpp:73-87), sorted by score."""
     gray = np.ascontiguousarray(gray, dtype=np.uint8)

@@ -325,6 +325,35 @@ inline std::vector<int32_t> selectNewLandmarks(const std::vector<vslam_feature> 
     return sel;
 }
 
+// generateOpticalRay(param, pixel, p), src/SLAM.cpp:876-903: the ray of a pixel in camera coordinates, optical_ray_length long in z.
+inline Vector generateOpticalRay(const CameraParameters &param, double u, double v, double optical_ray_length)
+{
+    Vector r(3);
+    if (vslam_optical_ray(&param.cam, u, v, optical_ray_length, r.data()) != 0) throw std::runtime_error("vslam: generateOpticalRay: unusable camera constants");
+    return r;
+}
+// initializeNewLandmark(...), src/SLAM.cpp:905-941, for all keypoints selected in a frame at once: the predicted state
+// (mup, Sp) and the filtered state (muEKF, SEKF) grow by three rows per keypoint; Sp and SEKF get kappa on the new
+// diagonal, mup the points on the optical rays, muEKF zeros (src/SLAM.cpp:908-915,929).  The Landmark bookkeeping
+// (src/SLAM.cpp:931-937) stays with the caller.
+template <class Vec, class Mat>
+void initializeNewLandmarks(Vec &mup, Mat &Sp, Vec &muEKF, Mat &SEKF, const std::vector<KeyPoint> &keypoints, const CameraParameters &param,
+                            double optical_ray_length, double kappa)
+{
+    const int n = (int)mup.size(), M = (int)keypoints.size(), m = n + 3 * M;
+    if (M == 0) return;
+    std::vector<double> px(2 * (size_t)M);
+    for (int t = 0; t < M; ++t) { px[2 * t] = keypoints[(size_t)t].x; px[2 * t + 1] = keypoints[(size_t)t].y; }
+    Vec mu_in = mup, muE_in = muEKF;
+    Mat S_in = Sp, SE_in = SEKF;
+    mup.resize(m, 1); Sp.resize(m, m); muEKF.resize(m, 1); SEKF.resize(m, m);
+    check(vslam_initialize_landmarks(context(), &param.cam, mu_in.data(), S_in.data(), n, (int)S_in.rows(), px.data(), M, optical_ray_length,
+                                     kappa, mup.data(), Sp.data(), m));
+    check(vslam_initialize_landmarks(context(), &param.cam, muE_in.data(), SE_in.data(), n, (int)SE_in.rows(), px.data(), M,
+                                     optical_ray_length, kappa, muEKF.data(), SEKF.data(), m));
+    for (int i = n; i < m; ++i) muEKF(i) = 0.0;
+}
+
 struct Match { int queryIdx, trainIdx; float distance; };       // the fields of cv::DMatch the caller reads
 inline void matchHamming(const uint8_t *query, int nq, const uint8_t *train, int nt, int desc_bytes, std::vector<Match> &matches)
 {
