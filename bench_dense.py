@@ -118,6 +118,24 @@ def run_dense_leg(ctx, dev, stream):
     torch.cuda.synchronize()
     frame["select_new_landmarks_64_frames_ms"] = e0.elapsed_time(e1) / 10
     frame["select_new_landmarks_mean_taken"] = float(sel_cnt.float().mean().item())
+    # initialisation of the selected keypoints: a device-resident state of 150 landmarks grows by 50
+    n_i, M_i = 12 + 3 * 150, 50
+    gen.manual_seed(9)
+    i_mu = torch.randn(n_i, dtype=torch.float64, device=dev, generator=gen) * 0.1
+    i_S = torch.triu(torch.randn((n_i, n_i), dtype=torch.float64, device=dev, generator=gen)).T.contiguous()
+    i_px = torch.stack([torch.rand(M_i, dtype=torch.float64, device=dev, generator=gen) * 1400 + 250,
+                        torch.rand(M_i, dtype=torch.float64, device=dev, generator=gen) * 880 + 100], dim=1).contiguous()
+    m_i = n_i + 3 * M_i
+    i_mo = torch.zeros(m_i, dtype=torch.float64, device=dev)
+    i_So = torch.zeros((m_i, m_i), dtype=torch.float64, device=dev)
+    api.initialize_landmarks_dev(ctx, cam, i_mu, i_S, i_px, i_mo, i_So)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(20):
+        api.initialize_landmarks_dev(ctx, cam, i_mu, i_S, i_px, i_mo, i_So)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    frame["initialize_50_landmarks_n462_ms"] = e0.elapsed_time(e1) / 20
     frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
     # a bank of independent filters on one GPU: one context (stream + workspace) per host thread
