@@ -178,6 +178,15 @@ def main():
     all_vals = sharding.gather_to_root(val)
     gathered_ok = None if all_vals is None else bool(all(torch.isfinite(v).all().item() for v in all_vals) and len(all_vals) == world)
 
+    # the two kernels of the call apart (outside the timed region): events inside the library, on its stream
+    ctx.set_kernel_timing(True)
+    split = []
+    for _ in range(20):
+        step()
+        split.append(ctx.last_point_loglik_times())
+    ctx.set_kernel_timing(False)
+    terms_ms, assemble_ms = (float(np.mean([s_[i] for s_ in split])) for i in (0, 1))
+
     # single-instance latency of the same update (launch-latency bound; reported, not the headline)
     x1, y1, v1 = x[:1], y[:1], vis[:1]
     for _ in range(5):
@@ -224,7 +233,11 @@ def main():
                        "parallelism": "replicated instances, no collective"},
             "roofline": {"bound": "hbm", "kernel": "loglik_terms_kernel + loglik_assemble_kernel (one point_loglik call)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms},
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
+                         "kernels_apart": {"loglik_terms_kernel_ms": terms_ms, "loglik_assemble_kernel_ms": assemble_ms,
+                                           "assemble_alone_frac": alg / (assemble_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "events recorded by the library between its two launches; achieved/frac "
+                                                   "above price the whole call (both kernels and the gap between them)"}},
             "results_gathered_to_root": gathered_ok,
             "single_instance_latency_us": single_us,
             "single_instance_updates_per_s": L / (single_us * 1e-6),

@@ -129,6 +129,12 @@ vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam_camera *ca
                                           const uint8_t *visible, size_t stride_vis, double sigma,
                                           double *value, double *g, size_t stride_g,
                                           double *H, int ldH, size_t stride_H, int32_t *code);
+/* Measurement aid without a counterpart in the reference: with timing on, the batched call above records events
+ * around its two kernels (per-landmark terms; assembly of the dense Hessian) whenever it takes its two-kernel form
+ * (batch * n * n * 8 >= 32 MiB), and the second function waits for them and returns the two durations of the last
+ * such call in milliseconds.  Off by default; the events cost a few microseconds per call. */
+vslam_status vslam_ctx_set_kernel_timing(vslam_ctx *ctx, int on);
+vslam_status vslam_ctx_last_point_loglik_times(vslam_ctx *ctx, double *terms_ms, double *assemble_ms);
 
 /* ---- Gaussian algebra ----
  * logGaussian x3, src/gaussian.hpp:30-74.  S upper triangular sqrt-covariance. */

@@ -45,6 +45,16 @@ class Context:
     def synchronize(self):
         check(self._L.vslam_ctx_synchronize(self.ptr), self.ptr)
 
+    def set_kernel_timing(self, on):
+        """Measurement aid: events around the two kernels of the batched point log-likelihood."""
+        check(self._L.vslam_ctx_set_kernel_timing(self.ptr, int(bool(on))), self.ptr)
+
+    def last_point_loglik_times(self):
+        """(terms_ms, assemble_ms) of the last timed two-kernel point_loglik_batch_dev call; waits for it."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(self._L.vslam_ctx_last_point_loglik_times(self.ptr, C.byref(a), C.byref(b)), self.ptr)
+        return a.value, b.value
+
     def close(self):
         if self.ptr:
             self._L.vslam_ctx_destroy(self.ptr)

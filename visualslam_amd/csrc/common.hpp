@@ -34,6 +34,9 @@ struct vslam_ctx {
     int *flags_host = nullptr;   // pinned mirror read by stream_finish
     int trs_solver = 0;          // VSLAM_TRS_EIG (default) / VSLAM_TRS_CHOLESKY
     int trs_last = -1;           // route the last measurement update took (-1: none yet)
+    bool time_kernels = false;   // measurement aid: events around the two kernels of the batched log-likelihood
+    hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+    bool tev_recorded = false;
     char err[512] = {0};
 };
 

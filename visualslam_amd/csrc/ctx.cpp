@@ -229,6 +229,7 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 3; ++i) if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -418,9 +418,13 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
         Arena ar(ctx->scratch);
         t.rec = ar.take<double>(rec_doubles);
         t.part = ar.take<double>(part_doubles);
+        const bool timed = ctx->time_kernels && ctx->tev[0];
+        if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[0], ctx->stream));
         hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), block, 0, ctx->stream, cam, t);
+        if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[1], ctx->stream));
         const size_t lds = (size_t)((kSliceBytes / 8) / (3 * n) + 3) * kRecFields * sizeof(double);
         hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), block, lds, ctx->stream, t);
+        if (timed) { VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[2], ctx->stream)); ctx->tev_recorded = true; }
     } else if (H) {
         dim3 grid(1 + panels, batch);
         hipLaunchKernelGGL(point_loglik_kernel<2>, grid, block, (size_t)a.P * 27 * sizeof(double), ctx->stream, cam, a);
@@ -436,6 +440,31 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
 }  // namespace vslam
 
 using namespace vslam;
+
+extern "C" vslam_status vslam_ctx_set_kernel_timing(vslam_ctx *ctx, int on)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on)
+        for (int i = 0; i < 3; ++i)
+            if (!ctx->tev[i]) VSLAM_HIP_TRY(ctx, hipEventCreate(&ctx->tev[i]));
+    ctx->time_kernels = on != 0;
+    ctx->tev_recorded = false;
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_ctx_last_point_loglik_times(vslam_ctx *ctx, double *terms_ms, double *assemble_ms)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!terms_ms || !assemble_ms) return fail(ctx, VSLAM_ERR_ARG, "last_point_loglik_times: null pointer");
+    if (!ctx->tev_recorded) return fail(ctx, VSLAM_ERR_ARG, "last_point_loglik_times: no timed two-kernel call since timing was switched on");
+    VSLAM_HIP_TRY(ctx, hipEventSynchronize(ctx->tev[2]));
+    float a = 0.f, b = 0.f;
+    VSLAM_HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->tev[0], ctx->tev[1]));
+    VSLAM_HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->tev[1], ctx->tev[2]));
+    *terms_ms = a; *assemble_ms = b;
+    return VSLAM_OK;
+}
 
 extern "C" vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, int batch, int n,
                                                      const double *x, size_t stride_x, const double *y, size_t stride_y,
