@@ -351,6 +351,12 @@ vslam_status vslam_initialize_landmarks(vslam_ctx *ctx, const vslam_camera *cam,
 vslam_status vslam_initialize_landmarks_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n, int ldS,
                                             const double *pixels, int M, double ray_length, double kappa,
                                             double *mu_out, double *S_out, int ldSout);
+/* Device-pointer batch of independent filters that take in the same number of keypoints: filter b reads mu + b*n,
+ * S + b*n*n (ld n), pixels + b*2*M and writes mu_out + b*(n+3M), S_out + b*(n+3M)^2 (ld n+3M).  Queued, not
+ * synchronised. */
+vslam_status vslam_initialize_landmarks_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n,
+                                                  int batch, const double *pixels, int M, double ray_length, double kappa,
+                                                  double *mu_out, double *S_out);
 
 /* FAST-9/16 with non-maximum suppression, the first stage of cv::ORB::detect as the reference configures
  * it (src/imagefeatures.cpp:73-87, fastThreshold 20).  OpenCV's code is not part of the reference, so the

@@ -128,6 +128,7 @@ def _declare(L):
         "vslam_select_new_landmarks_batch_dev": [_vp, _vp, _sz, _vp, _i, _vp, _sz, _vp, _i, C.POINTER(SelectParams), _i, _vp, _i, _vp],
         "vslam_initialize_landmarks": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _i],
         "vslam_initialize_landmarks_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp, _i],
+        "vslam_initialize_landmarks_batch_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp],
         "vslam_fast9_detect": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_fast9_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],

@@ -401,6 +401,15 @@ def initialize_landmarks_dev(ctx, cam, mu, S, pixels, mu_out, S_out, ray_length=
                                                 float(kappa), _tpc(mu_out), _tpc(S_out), m), ctx.ptr)
 
 
+def initialize_landmarks_batch_dev(ctx, cam, mu, S, pixels, mu_out, S_out, ray_length=8.0, kappa=0.5):
+    """A bank of filters, torch tensors on the GPU: mu (B, n), S (B, n, n) each column-major, pixels (B, M, 2) f64,
+    mu_out (B, n + 3M), S_out (B, n + 3M, n + 3M) each column-major."""
+    B, n = mu.shape
+    M = pixels.shape[1]
+    check(ctx._L.vslam_initialize_landmarks_batch_dev(ctx.ptr, C.byref(cam), _tpc(mu), _tpc(S), n, B, _tpc(pixels), M, float(ray_length),
+                                                      float(kappa), _tpc(mu_out), _tpc(S_out)), ctx.ptr)
+
+
 def fast9_detect(ctx, gray, threshold=20, nonmax=True, max_features=16384, cap=None, stride=None):
     """FAST-9/16 keypoints (first stage of cv::ORB::detect, reference src/imagefeatures.cpp:73-87), sorted by score."""
     gray = np.ascontiguousarray(gray, dtype=np.uint8)

@@ -42,9 +42,11 @@ __host__ __device__ inline void undistorted_ray(const RayK &k, double u, double 
 }
 
 // mu_out[0..n) = mu, mu_out[n + 3 t ..] = landmark t on its optical ray
+// (instance blockIdx.y of a bank: inputs n, n*n, 2*M and outputs n+3M, (n+3M)^2 doubles apart when batched)
 __global__ void init_mu_kernel(const double *mu, int n, const double *pixels, int M, RayK k, double *mu_out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    mu += (size_t)blockIdx.y * n; pixels += (size_t)blockIdx.y * 2 * M; mu_out += (size_t)blockIdx.y * (n + 3 * M);
     if (i < n) { mu_out[i] = mu[i]; return; }
     const int t = i - n;
     if (t >= M) return;
@@ -62,6 +64,7 @@ __global__ void init_mu_kernel(const double *mu, int n, const double *pixels, in
 __global__ void init_S_kernel(const double *S, int ldS, int n, int m, double kappa, double *S_out, int ldo)
 {
     const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    S += (size_t)blockIdx.z * ldS * n; S_out += (size_t)blockIdx.z * ldo * m;
     if (r >= m) return;
     double v = (r == c) ? kappa : 0.0;
     if (r < n && c < n) v = S[(size_t)c * ldS + r];
@@ -95,11 +98,11 @@ static vslam_status check_init(vslam_ctx *ctx, const vslam_camera *cam, const vo
 }
 
 static vslam_status launch_init(vslam_ctx *ctx, const RayK &k, const double *mu, const double *S, int n, int ldS, const double *pixels, int M,
-                                double kappa, double *mu_out, double *S_out, int ldSout)
+                                double kappa, double *mu_out, double *S_out, int ldSout, int batch = 1)
 {
     const int m = n + 3 * M;
-    hipLaunchKernelGGL(init_mu_kernel, dim3((n + M + 255) / 256), dim3(256), 0, ctx->stream, mu, n, pixels, M, k, mu_out);
-    hipLaunchKernelGGL(init_S_kernel, dim3((m + 255) / 256, m), dim3(256), 0, ctx->stream, S, ldS, n, m, kappa, S_out, ldSout);
+    hipLaunchKernelGGL(init_mu_kernel, dim3((n + M + 255) / 256, batch), dim3(256), 0, ctx->stream, mu, n, pixels, M, k, mu_out);
+    hipLaunchKernelGGL(init_S_kernel, dim3((m + 255) / 256, m, batch), dim3(256), 0, ctx->stream, S, ldS, n, m, kappa, S_out, ldSout);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -125,6 +128,18 @@ extern "C" vslam_status vslam_initialize_landmarks_dev(vslam_ctx *ctx, const vsl
     VSLAM_TRY(check_init(ctx, cam, mu, S, n, ldS, pixels, M, ray_length, kappa, mu_out, S_out, ldSout, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_init(ctx, k, mu, S, n, ldS, pixels, M, kappa, mu_out, S_out, ldSout);
+}
+
+extern "C" vslam_status vslam_initialize_landmarks_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n,
+                                                             int batch, const double *pixels, int M, double ray_length, double kappa,
+                                                             double *mu_out, double *S_out)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    RayK k;
+    VSLAM_TRY(check_init(ctx, cam, mu, S, n, n, pixels, M, ray_length, kappa, mu_out, S_out, n + 3 * M, &k));
+    if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "initialize_landmarks: batch=%d out of range", batch);
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_init(ctx, k, mu, S, n, n, pixels, M, kappa, mu_out, S_out, n + 3 * M, batch);
 }
 
 extern "C" vslam_status vslam_initialize_landmarks(vslam_ctx *ctx, const vslam_camera *cam, const double *mu, const double *S, int n, int ldS,
