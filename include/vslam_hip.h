@@ -272,6 +272,13 @@ vslam_status vslam_remove_landmark(vslam_ctx *ctx, const double *mu, const doubl
  * synchronised (vslam_remove_landmark checks the triangularity itself). */
 vslam_status vslam_remove_landmark_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int ldS, int j,
                                        double *mu_out, double *S_out, int ldSout, int s_is_upper);
+/* Device-pointer batch of independent filters with upper-triangular factors (src/SLAM.cpp:796-820 per filter):
+ * filter b drops landmark j_each[b] (device array) from mu + b*n, S + b*n*n (ld n) into mu_out + b*(n-3),
+ * S_out + b*(n-3)^2 (ld n-3); one workgroup re-triangularises one filter.  status (device, batch entries, may
+ * be NULL): 0, or 1 for an index outside 0..L-1, whose outputs are left untouched.  The strict lower part of S
+ * is not read.  Queued on the context's stream, not synchronised. */
+vslam_status vslam_remove_landmark_batch_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int batch, const int32_t *j_each,
+                                             double *mu_out, double *S_out, int32_t *status);
 
 /* ---- descriptor matching ----
  * cv::BFMatcher(cv::NORM_HAMMING).match(query, train, matches), src/SLAM.cpp:222,355: for each of the

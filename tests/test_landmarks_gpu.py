@@ -93,6 +93,39 @@ def test_remove_landmark_dev_matches_host_entry(ctx, upper):
     assert rel_err(dSo.cpu().numpy().T, S0) < 1e-11
 
 
+def test_remove_landmark_bank(ctx):
+    """A bank of filters, each dropping its own landmark (first, last, in between), one with an index outside
+    the map: results equal the single-filter entry bit for bit, the bad one is reported and left untouched."""
+    import torch
+    from visualslam_amd import api
+    n, B = 162, 6
+    L = (n - 12) // 3
+    js = [0, L - 1, 7, 31, L, 20]                                       # L is outside 0..L-1
+    rng = np.random.default_rng(23)
+    mus = rng.standard_normal((B, n))
+    Ss = np.stack([np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n) for _ in range(B)])
+    Ss[2] += np.tril(rng.standard_normal((n, n)), -1)                   # the strict lower part must not be read
+    dev = torch.device("cuda:0")
+    dmu = torch.tensor(mus, device=dev)
+    dS = torch.tensor(np.ascontiguousarray(Ss.transpose(0, 2, 1)), device=dev)
+    dj = torch.tensor(js, dtype=torch.int32, device=dev)
+    dmo = torch.full((B, n - 3), float("nan"), dtype=torch.float64, device=dev)
+    dSo = torch.full((B, n - 3, n - 3), float("nan"), dtype=torch.float64, device=dev)
+    dst = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    api.remove_landmark_batch_dev(ctx, dmu, dS, dj, dmo, dSo, dst)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    mo, So, st = dmo.cpu().numpy(), dSo.cpu().numpy(), dst.cpu().numpy()
+    assert st.tolist() == [0, 0, 0, 0, 1, 0]
+    for b in range(B):
+        if st[b]:
+            assert np.isnan(mo[b]).all() and np.isnan(So[b]).all()
+            continue
+        mu0, S0 = api.remove_landmark(ctx, mus[b], np.triu(Ss[b]), js[b])
+        assert np.array_equal(mo[b], mu0)
+        assert np.array_equal(So[b].T, S0)
+
+
 def test_remove_landmark_general_square_factor(ctx):
     """A factor that is not upper triangular goes through the dense QR; the marginal covariance is what counts."""
     from oracle import pyoracle as orc

@@ -120,6 +120,7 @@ def _declare(L):
         "vslam_time_update_batch_dev": [_vp, _vp, _vp, _i, _i, _vp, _vp, _d, _vp, _vp, _i],
         "vslam_remove_landmark": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i],
         "vslam_remove_landmark_dev": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i],
+        "vslam_remove_landmark_batch_dev": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
         "vslam_match_hamming": [_vp, _vp, _i, _vp, _i, _i, _vp, _vp],
         "vslam_match_hamming_batch_dev": [_vp, _vp, _sz, _i, _vp, _sz, _i, _vp, _i, _i, _vp, _vp],
         "vslam_corner_detect": [_vp, _vp, _i, _i, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],

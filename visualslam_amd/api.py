@@ -478,6 +478,14 @@ def remove_landmark_dev(ctx, mu, S, j, mu_out, S_out, s_is_upper=True):
                                            int(bool(s_is_upper))), ctx.ptr)
 
 
+def remove_landmark_batch_dev(ctx, mu, S, j_each, mu_out, S_out, status=None):
+    """A bank of filters with upper-triangular factors, torch tensors on the GPU: mu (B, n), S (B, n, n) each column-major,
+    j_each (B,) int32, mu_out (B, n-3), S_out (B, n-3, n-3) each column-major, status (B,) int32 or None."""
+    B, n = mu.shape
+    check(ctx._L.vslam_remove_landmark_batch_dev(ctx.ptr, _tpc(mu), _tpc(S), n, B, _tpc(j_each), _tpc(mu_out), _tpc(S_out), _tpc(status)),
+          ctx.ptr)
+
+
 def match_hamming_batch_dev(ctx, query, train, idx, dist=None, nt_each=None):
     """torch u8 tensors on the GPU: query (B, nq, bytes), train (B, nt, bytes); idx/dist (B, nq) int32."""
     B, nq, nb = query.shape

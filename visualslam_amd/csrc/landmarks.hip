@@ -116,7 +116,7 @@ __device__ __forceinline__ void rm_apply(const double (*Pm)[RM_W], const double 
 }
 
 // Whole factorisation by one workgroup (n up to about a thousand: the later columns fit a few per thread).
-__global__ __launch_bounds__(RM_T) void rm_qr_kernel(double *A, int lda, int n, int m, int c0)
+__device__ __forceinline__ void rm_qr_workgroup(double *A, int lda, int n, int m, int c0)
 {
     __shared__ double P[3][RM_W];
     __shared__ double taus[RM_W];
@@ -133,6 +133,52 @@ __global__ __launch_bounds__(RM_T) void rm_qr_kernel(double *A, int lda, int n, 
         rm_apply(P, taus, A, lda, n, m, j0, j0 + w, tid, RM_T);
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(RM_T) void rm_qr_kernel(double *A, int lda, int n, int m, int c0) { rm_qr_workgroup(A, lda, n, m, c0); }
+
+// ---- a bank of filters: instance b drops landmark j_each[b]; an index outside 0..L-1 leaves the instance's outputs
+// untouched and is reported in status[b] ----
+__device__ __forceinline__ bool rm_bank_index(const int *j_each, int b, int n, int &c0)
+{
+    const int j = j_each[b];
+    c0 = 12 + 3 * j;
+    return j >= 0 && j < (n - 12) / 3;
+}
+
+__global__ void rm_bank_rows_kernel(const double *mu, int n, const int *j_each, double *out, int *status)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    int c0;
+    const bool ok = rm_bank_index(j_each, b, n, c0);
+    if (i == 0 && status) status[b] = ok ? 0 : 1;
+    if (ok && i < n - 3) out[(size_t)b * (n - 3) + i] = mu[(size_t)b * n + (i < c0 ? i : i + 3)];
+}
+
+__global__ void rm_bank_columns_kernel(const double *S, int n, const int *j_each, double *A)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    int c0;
+    if (!rm_bank_index(j_each, b, n, c0)) return;
+    const int cs = c < c0 ? c : c + 3;
+    const size_t o = (size_t)b * n * n;
+    if (r < n) A[o + (size_t)c * n + r] = (r <= cs) ? S[o + (size_t)cs * n + r] : 0.0;
+}
+
+__global__ __launch_bounds__(RM_T) void rm_bank_qr_kernel(double *A, int n, const int *j_each)
+{
+    const int b = blockIdx.x;
+    int c0;
+    if (!rm_bank_index(j_each, b, n, c0)) return;
+    rm_qr_workgroup(A + (size_t)b * n * n, n, n, n - 3, c0);
+}
+
+__global__ void rm_bank_copy_out_kernel(const double *A, int n, const int *j_each, double *S_out)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z, m = n - 3;
+    int c0;
+    if (!rm_bank_index(j_each, b, n, c0)) return;
+    if (r < m) S_out[(size_t)b * m * m + (size_t)c * m + r] = (r <= c) ? A[(size_t)b * n * n + (size_t)c * n + r] : 0.0;
 }
 
 // Large n: one launch pair per panel (reflectors through Vg: 3 * RM_W entries and RM_W taus).
@@ -227,6 +273,28 @@ extern "C" vslam_status vslam_remove_landmark_dev(vslam_ctx *ctx, const double *
         VSLAM_TRY(qr_upper_dev(ctx, dA, n, m, n, 0, 1, qws));
     }
     hipLaunchKernelGGL(rm_copy_out_kernel, dim3((m + 255) / 256, m), dim3(256), 0, s, dA, n, m, S_out, ldSout);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_remove_landmark_batch_dev(vslam_ctx *ctx, const double *mu, const double *S, int n, int batch, const int32_t *j_each,
+                                                        double *mu_out, double *S_out, int32_t *status)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!mu || !S || !j_each || !mu_out || !S_out) return fail(ctx, VSLAM_ERR_ARG, "remove_landmark: null pointer");
+    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "remove_landmark: n=%d is not 12+3L (L >= 1)", n);
+    if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "remove_landmark: batch=%d out of range", batch);
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int m = n - 3;
+    const size_t nn = (size_t)n * n;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(nn * 8 * (size_t)batch)));
+    Arena ar(ctx->ws);
+    double *dA = ar.take<double>(nn * (size_t)batch);
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(rm_bank_rows_kernel, dim3((m + 255) / 256, batch), dim3(256), 0, s, mu, n, j_each, mu_out, status);
+    hipLaunchKernelGGL(rm_bank_columns_kernel, dim3((n + 255) / 256, m, batch), dim3(256), 0, s, S, n, j_each, dA);
+    hipLaunchKernelGGL(rm_bank_qr_kernel, dim3(batch), dim3(RM_T), 0, s, dA, n, j_each);
+    hipLaunchKernelGGL(rm_bank_copy_out_kernel, dim3((m + 255) / 256, m, batch), dim3(256), 0, s, dA, n, j_each, S_out);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
