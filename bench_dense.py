@@ -136,6 +136,25 @@ def run_dense_leg(ctx, dev, stream):
     e1.record(stream)
     torch.cuda.synchronize()
     frame["initialize_50_landmarks_n462_ms"] = e0.elapsed_time(e1) / 20
+    # landmark removal in a bank of 512 filters of 150 landmarks, each dropping its own landmark
+    Bb = 512
+    gen.manual_seed(10)
+    b_mu = torch.randn((Bb, n_i), dtype=torch.float64, device=dev, generator=gen)
+    b_S = (torch.triu(torch.randn((n_i, n_i), dtype=torch.float64, device=dev, generator=gen)) + 3.0 * torch.eye(n_i, dtype=torch.float64, device=dev))
+    b_S = b_S.T.contiguous().unsqueeze(0).repeat(Bb, 1, 1).contiguous()
+    b_j = torch.randint(0, 150, (Bb,), dtype=torch.int32, device=dev, generator=gen)
+    b_mo = torch.zeros((Bb, n_i - 3), dtype=torch.float64, device=dev)
+    b_So = torch.zeros((Bb, n_i - 3, n_i - 3), dtype=torch.float64, device=dev)
+    b_st = torch.zeros(Bb, dtype=torch.int32, device=dev)
+    api.remove_landmark_batch_dev(ctx, b_mu, b_S, b_j, b_mo, b_So, b_st)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(5):
+        api.remove_landmark_batch_dev(ctx, b_mu, b_S, b_j, b_mo, b_So, b_st)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    frame["remove_landmark_512_filters_ms"] = e0.elapsed_time(e1) / 5
+    del b_mu, b_S, b_mo, b_So
     frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
     # a bank of independent filters on one GPU: one context (stream + workspace) per host thread
