@@ -150,6 +150,11 @@ vslam_status vslam_affine_sqrt(vslam_ctx *ctx, const double *S, int n, int ldS,
 vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *cam, const double *mux,
                                  const double *Sxx, int n, int ldS, int layout,
                                  double *muy, double *Syy, int ldSyy, int32_t *code);
+/* Device-pointer batch of independent filters (the same transform per filter, src/gaussian.hpp:85-131 with the
+ * bundle of src/measurementPointLandmark.cpp:13-70): filter b reads mux + b*n, Sxx + b*n*n (ld n) and writes
+ * muy + b*2L, Syy + b*(2L)^2 (ld 2L, upper triangular), code + b*L (may be NULL).  Queued, not synchronised. */
+vslam_status vslam_affine_bundle_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mux, const double *Sxx, int n,
+                                           int batch, int layout, double *muy, double *Syy, int32_t *code);
 /* Eigen::HouseholderQR + triangularView<Upper>, src/gaussian.hpp:121-124,515-516,
  * src/SLAM.cpp:810-819: in place; R in the upper triangle, zeros below. */
 vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int cols, int lda);

@@ -72,6 +72,35 @@ def test_affine_bundle_fused_vs_oracle(ctx, gcam, ocam, layout, L, seed):
     assert rel_err(api.affine_sqrt(ctx, sc.S, C, SR), Syy0) <= TOL
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_affine_bundle_bank_vs_oracle(ctx, gcam, ocam, layout):
+    """The same transform for a bank of device-resident filters: every filter against the oracle."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    B, L = 5, 40
+    n, m = 12 + 3 * L, 2 * L
+    scs = [syn.Scene(L, 300 + b) for b in range(B)]
+    xs = np.stack([sc.x for sc in scs])
+    xs[:, 3:6] = [0.02, -0.01, 0.03]
+    dev = torch.device("cuda:0")
+    dx = torch.tensor(xs, device=dev)
+    dS = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    dmu = torch.full((B, m), float("nan"), dtype=torch.float64, device=dev)
+    dSy = torch.full((B, m, m), float("nan"), dtype=torch.float64, device=dev)
+    dc = torch.full((B, L), -1, dtype=torch.int32, device=dev)
+    api.affine_bundle_batch_dev(ctx, gcam, dx, dS, dmu, dSy, dc, layout)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    muy, Syy, code = dmu.cpu().numpy(), dSy.cpu().numpy(), dc.cpu().numpy()
+    for b in range(B):
+        h0, SR0, C0, code0 = orc.bundle_measure(xs[b], ocam, layout)
+        Syy0 = orc.affine_sqrt(scs[b].S, C0, SR0)
+        assert np.array_equal(code[b], code0) and rel_err(muy[b], h0) <= TOL
+        assert rel_err(Syy[b].T, Syy0) <= TOL
+        assert not np.tril(Syy[b].T, -1).any()
+
+
 def test_condition_on_marginal(ctx):
     from oracle import pyoracle as orc
     from visualslam_amd import api

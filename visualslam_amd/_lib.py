@@ -103,6 +103,7 @@ def _declare(L):
         "vslam_log_gaussian": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
         "vslam_affine_sqrt": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i],
         "vslam_affine_bundle": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+        "vslam_affine_bundle_batch_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
         "vslam_qr_upper": [_vp, _vp, _i, _i, _i],
         "vslam_qr_upper_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i],
         "vslam_iekf_post_sqrt": [_vp, _vp, _vp, _i, _vp],

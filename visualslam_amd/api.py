@@ -478,6 +478,14 @@ def remove_landmark_dev(ctx, mu, S, j, mu_out, S_out, s_is_upper=True):
                                            int(bool(s_is_upper))), ctx.ptr)
 
 
+def affine_bundle_batch_dev(ctx, cam, mux, Sxx, muy, Syy, code=None, layout=LAYOUT_COMPAT):
+    """A bank of filters, torch tensors on the GPU: mux (B, n), Sxx (B, n, n) each column-major, muy (B, 2L),
+    Syy (B, 2L, 2L) each column-major, code (B, L) int32 or None."""
+    B, n = mux.shape
+    check(ctx._L.vslam_affine_bundle_batch_dev(ctx.ptr, C.byref(cam), _tpc(mux), _tpc(Sxx), n, B, layout, _tpc(muy), _tpc(Syy), _tpc(code)),
+          ctx.ptr)
+
+
 def remove_landmark_batch_dev(ctx, mu, S, j_each, mu_out, S_out, status=None):
     """A bank of filters with upper-triangular factors, torch tensors on the GPU: mu (B, n), S (B, n, n) each column-major,
     j_each (B,) int32, mu_out (B, n-3), S_out (B, n-3, n-3) each column-major, status (B,) int32 or None."""

@@ -72,10 +72,13 @@ __device__ __forceinline__ Pose rot_pose2(const double *x, int layout, const Pos
     return r;
 }
 
+// (blockIdx.y: instance of a bank; x, h, code and rec are 12+3L, 2L, L and L entries apart)
 __global__ void bundle_jac_compact_kernel(CamK k, const double *x, int L, int layout, double *h, int32_t *code, JacRec *rec)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= L) return;
+    x += (size_t)blockIdx.y * (12 + 3 * L); h += (size_t)blockIdx.y * 2 * L; rec += (size_t)blockIdx.y * L;
+    if (code) code += (size_t)blockIdx.y * L;
     const Pose p = make_pose(x + 6);
     const Pose pr = rot_pose2(x, layout, p);
     const double *r = x + 12 + 3 * j;
@@ -117,12 +120,14 @@ __global__ void bundle_jac_compact_kernel(CamK k, const double *x, int L, int la
 // Top block of affineTransform's QR input without materialising C:
 //   A[i, 2j+k] = sum_a S[i, cam0+a] Jc[k][a] + sum_a S[i, lm0+3j+a] Jl[k][a]      (i < n)
 // and the bottom block SR = 0.01 I (rows n..n+2L).  One thread per (row, landmark).
+// (blockIdx.z: instance of a bank; S, rec and A are ldS*n, L and ldA*2L entries apart)
 __global__ __launch_bounds__(256) void s_times_ct_kernel(const double *S, int n, int ldS, const JacRec *rec, int L, int layout,
                                                          double *A, int ldA)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     const int m = 2 * L;
     if (i >= n + m) return;
+    S += (size_t)blockIdx.z * ldS * n; rec += (size_t)blockIdx.z * L; A += (size_t)blockIdx.z * ldA * m;
     double *c0 = A + (size_t)(2 * j) * ldA, *c1 = c0 + ldA;
     if (i >= n) {
         const int r = i - n;
@@ -144,6 +149,13 @@ __global__ __launch_bounds__(256) void s_times_ct_kernel(const double *S, int n,
         s0 += s * J.Jl[0][a]; s1 += s * J.Jl[1][a];
     }
     c0[i] = s0; c1[i] = s1;
+}
+
+// dst[b] (m x m, ld m) = leading m x m block of src[b] (ld lds, stride_src entries apart)
+__global__ void copy_block_batch_kernel(const double *src, int lds, size_t stride_src, double *dst, int m)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (r < m) dst[(size_t)blockIdx.z * m * m + (size_t)c * m + r] = src[(size_t)blockIdx.z * stride_src + (size_t)c * lds + r];
 }
 
 // mux_out[i] = mu[ny+i] + sum_k S2[k,i] t[k]   (src/gaussian.cpp:34)
@@ -271,6 +283,34 @@ extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *
     if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));
     VSLAM_TRY(d2h_2d(ctx, Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m));
     return stream_finish(ctx);
+}
+
+extern "C" vslam_status vslam_affine_bundle_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mux, const double *Sxx, int n,
+                                                      int batch, int layout, double *muy, double *Syy, int32_t *code)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!mux || !Sxx || !muy || !Syy) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
+    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: n=%d is not 12+3L", n);
+    if (layout != VSLAM_LAYOUT_COMPAT && layout != VSLAM_LAYOUT_STRICT) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: bad layout %d", layout);
+    if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: batch=%d out of range", batch);
+    const int L = (n - 12) / 3, m = 2 * L, rows = n + m;
+    CamK k;
+    VSLAM_TRY(resolve_camera(ctx, cam, &k));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t per_A = (size_t)rows * m;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad((size_t)batch * L * sizeof(JacRec)) + Arena::pad((size_t)batch * per_A * 8) + qr_ws_bytes(rows, m, batch)));
+    Arena ar(ctx->ws);
+    JacRec *rec = ar.take<JacRec>((size_t)batch * L);
+    double *dA = ar.take<double>((size_t)batch * per_A);
+    void *qws = ar.take<char>(qr_ws_bytes(rows, m, batch));
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(bundle_jac_compact_kernel, dim3((L + 63) / 64, batch), dim3(64), 0, s, k, mux, L, layout, muy, code, rec);
+    hipLaunchKernelGGL(s_times_ct_kernel, dim3((rows + 255) / 256, L, batch), dim3(256), 0, s, Sxx, n, n, rec, L, layout, dA, rows);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, per_A, batch, qws));
+    hipLaunchKernelGGL(copy_block_batch_kernel, dim3((m + 255) / 256, m, batch), dim3(256), 0, s, dA, rows, per_A, Syy, m);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
 }
 
 extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out)
