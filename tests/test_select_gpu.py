@@ -19,7 +19,8 @@ def _case(seed, K, L, spread=1.0):
 
 @pytest.mark.parametrize("seed,K,L,max_new,radius", [(0, 0, 0, 10, 150.0), (1, 1, 0, 10, 150.0), (2, 255, 3, 50, 150.0), (3, 256, 0, 50, 150.0),
                                                     (4, 257, 40, 50, 150.0), (5, 10000, 100, 50, 150.0), (6, 10000, 0, 1000, 20.0),
-                                                    (7, 3000, 150, 0, 150.0), (8, 5000, 10, 300, 0.0), (9, 2000, 5, 40, 60.5)])
+                                                    (7, 3000, 150, 0, 150.0), (8, 5000, 10, 300, 0.0), (9, 2000, 5, 40, 60.5),
+                                                    (10, 4000, 2048, 200, 12.0), (11, 4000, 5000, 200, 9.0)])   # maps at and beyond one LDS tile
 def test_selection_matches_oracle(ctx, seed, K, L, max_new, radius):
     from oracle import pyoracle as orc
     from visualslam_amd import api

@@ -6,7 +6,9 @@
 // features in chunks of 256: every thread tests its feature against the map and against the landmarks
 // taken so far (independent work), then the chunk is resolved in order -- the first surviving feature is
 // taken, the later ones of the chunk are tested against it, and so on -- which needs a few barriers per
-// taken landmark instead of one step per feature.
+// taken landmark instead of one step per feature.  The map is staged in LDS and tested in full by every
+// thread (no early exit: a loop without a carried dependency is several times faster than one that stops at
+// the first landmark in range).
 // Distances are formed as the reference forms them: float differences, float products and sum (this file
 // is compiled without FMA contraction), correctly rounded float square root, comparison with the double
 // threshold.  The loop index that pixelDistance leaves uninitialised is taken as 0.
@@ -19,6 +21,7 @@ namespace vslam {
 
 constexpr int SEL_T = 256;
 constexpr int SEL_MAX_NEW = 1024;
+constexpr int SEL_LM_TILE = 2048;
 
 struct SelArgs {
     const vslam_feature *feats; size_t stride_feats; const int32_t *k_each; int K;
@@ -39,6 +42,7 @@ __host__ __device__ inline bool sel_within(float lx, float ly, float x, float y,
 __global__ __launch_bounds__(SEL_T) void select_kernel(SelArgs a)
 {
     __shared__ float ax[SEL_MAX_NEW], ay[SEL_MAX_NEW];
+    __shared__ float mx[SEL_LM_TILE], my[SEL_LM_TILE];           // landmarks of the map, a tile at a time
     __shared__ int n_acc, first;
     const int b = blockIdx.x, tid = threadIdx.x;
     const vslam_feature *feats = a.feats + (size_t)b * a.stride_feats;
@@ -48,6 +52,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelArgs a)
     if (a.l_each) L = max(0, min(L, a.l_each[b]));
     int32_t *sel = a.selected + (size_t)b * a.cap;
     if (tid == 0) n_acc = 0;
+    const bool map_in_lds = L <= SEL_LM_TILE;                     // the usual case: staged once for all chunks
+    if (map_in_lds)
+        for (int l = tid; l < L; l += SEL_T) { mx[l] = lm[2 * l]; my[l] = lm[2 * l + 1]; }
     __syncthreads();
     for (int c0 = 0; c0 < K; c0 += SEL_T) {
         if (n_acc >= a.max_new) break;                            // uniform: n_acc only changes between barriers
@@ -59,8 +66,29 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelArgs a)
             fx = (float)f.x; fy = (float)f.y;
             cand = (double)f.score > a.fthr && a.wthr <= (double)fx && (double)fx <= (double)a.iw - a.wthr &&
                    a.hthr <= (double)fy && (double)fy <= (double)a.ih - a.hthr;
-            for (int l = 0; cand && l < L; ++l) cand = !sel_within(lm[2 * l], lm[2 * l + 1], fx, fy, a.dthr);
-            for (int l = 0; cand && l < seen; ++l) cand = !sel_within(ax[l], ay[l], fx, fy, a.dthr);
+        }
+        // against the map: every landmark is tested (no early exit, so that the loop carries no dependency)
+        for (int t0 = 0; t0 < L; t0 += SEL_LM_TILE) {
+            const int tl = min(SEL_LM_TILE, L - t0);
+            if (!map_in_lds) {
+                __syncthreads();
+                for (int l = tid; l < tl; l += SEL_T) { mx[l] = lm[2 * (t0 + l)]; my[l] = lm[2 * (t0 + l) + 1]; }
+                __syncthreads();
+            }
+            bool within = false;
+            int l = 0;
+            for (; l + 4 <= tl; l += 4) {
+                const bool w0 = sel_within(mx[l], my[l], fx, fy, a.dthr), w1 = sel_within(mx[l + 1], my[l + 1], fx, fy, a.dthr);
+                const bool w2 = sel_within(mx[l + 2], my[l + 2], fx, fy, a.dthr), w3 = sel_within(mx[l + 3], my[l + 3], fx, fy, a.dthr);
+                within |= (w0 | w1) | (w2 | w3);
+            }
+            for (; l < tl; ++l) within |= sel_within(mx[l], my[l], fx, fy, a.dthr);
+            cand = cand && !within;
+        }
+        {
+            bool within = false;
+            for (int l = 0; l < seen; ++l) within |= sel_within(ax[l], ay[l], fx, fy, a.dthr);
+            cand = cand && !within;
         }
         for (;;) {                                                // resolve the chunk in feature order
             __syncthreads();
