@@ -167,6 +167,20 @@ def run_dense_leg(ctx, dev, stream):
     e1.record(stream)
     torch.cuda.synchronize()
     frame["affine_bundle_512_filters_ms"] = e0.elapsed_time(e1) / 3
+    # ... and its data association against the frame's features (the density computed above stays on the device)
+    a_y = torch.tensor(np.ascontiguousarray(yf.T), device=dev).unsqueeze(0).repeat(Bb, 1, 1).contiguous()   # (B, m, 2)
+    a_idx = torch.zeros((Bb, 150), dtype=torch.int32, device=dev)
+    a_sur = torch.zeros(Bb, dtype=torch.float64, device=dev)
+    api.snn_density_batch_dev(ctx, a_my, a_Sy, a_y, 150, a_y.shape[1], 1920, 1080, a_idx, a_sur)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(3):
+        api.snn_density_batch_dev(ctx, a_my, a_Sy, a_y, 150, a_y.shape[1], 1920, 1080, a_idx, a_sur)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    frame["snn_density_512_filters_ms"] = e0.elapsed_time(e1) / 3
+    frame["snn_density_512_filters_mean_associated"] = float((a_idx >= 0).float().sum(dim=1).mean().item())
+    del a_y
     del b_mu, b_S, b_mo, b_So, a_mu, a_S, a_my, a_Sy
     frame["match_hamming_pairs_per_s"] = Bm * nq * nt / (mms * 1e-3)
     hctx.close()
