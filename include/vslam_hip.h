@@ -129,6 +129,20 @@ vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam_camera *ca
                                           const uint8_t *visible, size_t stride_vis, double sigma,
                                           double *value, double *g, size_t stride_g,
                                           double *H, int ldH, size_t stride_H, int32_t *code);
+/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc); it has no counterpart in the reference.  It calls no hipMalloc / hipFree: the
+ * per-landmark records and per-block pose sums between its two kernels live in a static device array of the
+ * library (about 10.7 MB per GPU, held until the process ends) whose address is looked up at context creation.
+ * Limits: batch * L <= 81920 landmarks and batch * ceil(L / 256) <= 4096, else VSLAM_ERR_CAPACITY; when H is
+ * given, ldH must equal n.  Results are those of vslam_point_loglik_batch_dev bit for bit (same kernels).
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (different streams or contexts)
+ * race; calls on one stream are ordered and safe. */
+vslam_status vslam_point_loglik_batch_dev_noalloc(vslam_ctx *ctx, const vslam_camera *cam, int batch, int n,
+                                                  const double *x, size_t stride_x,
+                                                  const double *y, size_t stride_y,
+                                                  const uint8_t *visible, size_t stride_vis, double sigma,
+                                                  double *value, double *g, size_t stride_g,
+                                                  double *H, int ldH, size_t stride_H, int32_t *code);
 /* Measurement aid without a counterpart in the reference: with timing on, the batched call above records events
  * around its two kernels (per-landmark terms; assembly of the dense Hessian) whenever it takes its two-kernel form
  * (batch * n * n * 8 >= 32 MiB), and the second function waits for them and returns the two durations of the last
@@ -190,7 +204,11 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
  * ld n, upper triangular), y (batch x 2L), visible (batch x L), mu_post and S_post like mu and S are
  * device pointers; fmin_code / iters / status are host arrays of `batch` entries (each may be NULL).
  * Every step of the trust-region iteration runs over the whole bank in one set of kernel launches,
- * on the Cholesky route described below (the reference's sequence of iterates per filter).
+ * on the Cholesky route described below.  Per filter the iterates follow the reference's to about
+ * 1e-10 relative, not bit for bit: the multiplier iteration of the trust-region subproblem also stops once
+ * |p| matches the radius to 1e-10 relative (with a collapsed trust region the reference's absolute test
+ * |1/Delta - 1/|p|| < sqrt(eps) asks for more digits than the quantity has), and the accept / radius tests
+ * on rho are discontinuous, so a last-bit difference can in principle change a decision.
  * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = its Hessian was not positive definite
  * at some iterate: its outputs are meaningless and the caller redoes that filter with
  * vslam_measurement_update_iekf.  Returns after the results are complete. */
@@ -203,8 +221,8 @@ vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, const vslam
  * EIG (default): as the reference, from a symmetric eigendecomposition of the Hessian taken on
  *      the host at every accepted iterate (O(n^3) scalar work per iterate).
  * CHOLESKY (opt-in, no counterpart in the reference): while the Hessian is positive definite,
- *      from Cholesky factors on the device -- the same secular-equation Newton iteration with
- *      the same iterates, no eigensolver; the posterior square root is the R factor of U^-T
+ *      from Cholesky factors on the device -- the same secular-equation Newton iteration (iterates equal to
+ *      about 1e-10 relative: see the stopping rule noted at vslam_measurement_update_iekf_batch_dev), no eigensolver; the posterior square root is the R factor of U^-T
  *      (equal to the reference's up to row signs).  An update that meets an indefinite Hessian
  *      is redone on the EIG route. */
 enum { VSLAM_TRS_EIG = 0, VSLAM_TRS_CHOLESKY = 1 };

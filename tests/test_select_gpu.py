@@ -31,6 +31,24 @@ def test_selection_matches_oracle(ctx, seed, K, L, max_new, radius):
     assert got.tolist() == want.tolist()
 
 
+@pytest.mark.parametrize("max_new", [1, 2, 3])
+def test_capacity_reached_inside_a_chunk_with_candidates_in_every_wave(ctx, max_new):
+    """One 256-keypoint chunk whose four wavefronts all hold candidates far apart from each other: the
+    capacity is reached while later wavefronts still have candidates to offer."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    K = 256
+    feats = np.zeros(K, dtype=orc.FEATURE_DTYPE)
+    feats["x"] = 300 + (np.arange(K) % 8) * 170                 # an 8 x 4 lattice of spots 170 px apart, repeated
+    feats["y"] = 150 + ((np.arange(K) // 8) % 4) * 170
+    feats["score"] = np.linspace(1e-3, 2e-4, K).astype(np.float32)
+    lm = np.zeros((0, 2), np.float32)
+    p = api.select_params(max_new=max_new)
+    want = orc.select_new_landmarks(feats, lm, 1e-4, 250, 100, 150.0, 1920, 1080, max_new)
+    got = api.select_new_landmarks(ctx, feats, lm, p)
+    assert got.tolist() == want.tolist() and got.size == max_new
+
+
 def test_selection_reference_scenario(ctx):
     """Keypoints of the corner detector on a synthetic frame, the reference's scenario-2 thresholds."""
     from oracle import pyoracle as orc
@@ -71,6 +89,7 @@ def test_selection_batch_dev(ctx):
     sel = torch.full((B, cap), -7, dtype=torch.int32, device=dev)
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     p = api.select_params(max_new=40)
+    torch.cuda.synchronize()                                      # the fills above ran on torch's stream, the call runs on the context's
     api.select_new_landmarks_batch_dev(ctx, feats, torch.tensor(k_each, device=dev), K, lms, torch.tensor(l_each, device=dev), L, p, sel, cnt)
     torch.cuda.synchronize()
     for b in range(B):

@@ -100,6 +100,8 @@ def _declare(L):
         "vslam_point_loglik": [_vp, C.POINTER(Camera), _vp, _i, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp],
         "vslam_point_loglik_batch_dev": [_vp, C.POINTER(Camera), _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _d,
                                          _vp, _vp, _sz, _vp, _i, _sz, _vp],
+        "vslam_point_loglik_batch_dev_noalloc": [_vp, C.POINTER(Camera), _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _d,
+                                                 _vp, _vp, _sz, _vp, _i, _sz, _vp],
         "vslam_log_gaussian": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
         "vslam_affine_sqrt": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _i],
         "vslam_affine_bundle": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],

@@ -437,14 +437,16 @@ def corner_response(ctx, gray, params):
 
 
 # ------------------------------------------------------------------ device-pointer calls (torch tensors)
-def point_loglik_batch_dev(ctx, cam, n, x, y, visible, sigma, value, g=None, H=None, code=None, ldH=None):
+def point_loglik_batch_dev(ctx, cam, n, x, y, visible, sigma, value, g=None, H=None, code=None, ldH=None, noalloc=False):
     """x (B,n) f64, y (B,2L) f64, visible (B,L) u8, value (B,) f64, g (B,n) f64,
     H (B,n,ldH) f64 holding each instance column-major, code (B,L) i32: torch
-    CUDA tensors, contiguous.  Queued on the context's stream, not synchronised."""
+    CUDA tensors, contiguous.  Queued on the context's stream, not synchronised.
+    noalloc=True takes the entry point that allocates nothing (static device scratch,
+    at most 81920 landmarks per call)."""
     B = x.shape[0]
-    L = (n - 12) // 3
     ld = n if ldH is None else ldH
-    check(ctx._L.vslam_point_loglik_batch_dev(
+    fn = ctx._L.vslam_point_loglik_batch_dev_noalloc if noalloc else ctx._L.vslam_point_loglik_batch_dev
+    check(fn(
         ctx.ptr, C.byref(cam), B, n, _tp(x), x.stride(0), _tp(y), y.stride(0), _tp(visible), visible.stride(0),
         float(sigma), _tp(value), _tp(g), 0 if g is None else g.stride(0),
         _tp(H), ld, 0 if H is None else H.stride(0), _tp(code)), ctx.ptr)

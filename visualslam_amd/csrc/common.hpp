@@ -26,6 +26,8 @@ struct vslam_ctx {
     void *pinned = nullptr;      // pinned host staging arena of the host-pointer entry points
     size_t pinned_bytes = 0, pinned_off = 0;
     std::vector<vslam_pending_copy> pending;
+    bool corner_lds_attr_set = false;   // corner.hip: large dynamic LDS sizes registered for this context's device
+    bool failed = false;         // an entry point returned an error: its staged copies are dropped, not completed
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up; [64..320) ready
@@ -49,6 +51,7 @@ inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
         va_start(ap, fmt);
         vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
         va_end(ap);
+        ctx->failed = true;      // device-to-host copies the failed call staged must not reach its host pointers later
     }
     return s;
 }
@@ -82,6 +85,9 @@ vslam_status h2d(vslam_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
 vslam_status d2h(vslam_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height);
 vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height);
+// Looks up, once per GPU, the device address of the static scratch array of the entry point that
+// allocates nothing (point_loglik.hip); called at context creation with the device current.
+vslam_status loglik_static_scratch_init(vslam_ctx *ctx);
 // Creates ctx->side and ctx->ev[] on first use.
 vslam_status side_stream_init(vslam_ctx *ctx);
 

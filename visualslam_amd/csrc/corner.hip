@@ -851,8 +851,9 @@ static vslam_status check_fast9(vslam_ctx *ctx, int w, int h, int stride, int th
 
 static vslam_status ensure_lds_attr(vslam_ctx *ctx)
 {
-    static bool done = false;
-    if (done) return VSLAM_OK;
+    // The attribute belongs to the function on the current device: one flag per context (a context is bound
+    // to one device and is not used from two threads at once).
+    if (ctx->corner_lds_attr_set) return VSLAM_OK;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     const int big = (int)tile_lds_bytes(2 * MAXHB + 1);
@@ -862,7 +863,7 @@ static vslam_status ensure_lds_attr(vslam_ctx *ctx)
         reinterpret_cast<const void *>(&corner_tile_kernel<1, false, 7>), reinterpret_cast<const void *>(&corner_tile_kernel<2, false, 7>),
         reinterpret_cast<const void *>(&corner_tile_kernel<3, false, 7>), reinterpret_cast<const void *>(&corner_tile_kernel<3, true, 7>)};
     for (const void *kfn : tile_kernels) VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    done = true;
+    ctx->corner_lds_attr_set = true;
     return VSLAM_OK;
 }
 

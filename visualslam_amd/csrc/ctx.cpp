@@ -47,6 +47,7 @@ vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes)
 static vslam_status pinned_take(vslam_ctx *ctx, size_t bytes, char **out)
 {
     const size_t need = (bytes + 255) & ~size_t(255);
+    if (ctx->failed) VSLAM_TRY(stream_sync(ctx));        // leftovers of a call that returned an error: drained and dropped
     if (ctx->pinned_off + need > ctx->pinned_bytes) {
         VSLAM_TRY(stream_sync(ctx));                     // everything staged so far is consumed; arena is empty again
         if (need > ctx->pinned_bytes) {
@@ -66,6 +67,14 @@ static vslam_status pinned_take(vslam_ctx *ctx, size_t bytes, char **out)
 vslam_status stream_sync(vslam_ctx *ctx)
 {
     VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->failed) {
+        // Copies staged by an entry point that then failed: their host destinations may be gone
+        // (temporaries of the caller, stack variables of the entry point).
+        ctx->failed = false;
+        ctx->pending.clear();
+        ctx->pinned_off = 0;
+        return VSLAM_OK;
+    }
     for (const vslam_pending_copy &c : ctx->pending) {
         const char *src = static_cast<const char *>(c.src);
         char *dst = static_cast<char *>(c.dst);
@@ -209,6 +218,11 @@ static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **
         return VSLAM_ERR_ALLOC;
     }
     c->flags_host[0] = 0;
+    if (loglik_static_scratch_init(c) != VSLAM_OK) {
+        std::fprintf(stderr, "libvslam_hip: %s\n", c->err);
+        vslam_ctx_destroy(c);
+        return VSLAM_ERR_DEVICE;
+    }
     *out = c;
     return VSLAM_OK;
 }

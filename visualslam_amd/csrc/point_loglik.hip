@@ -26,6 +26,8 @@
 // The kernel is HBM-write bound: 8 n^2 bytes of H per instance.
 #include "landmark_math.hpp"
 
+#include <mutex>
+
 namespace vslam {
 
 struct LoglikArgs {
@@ -386,11 +388,34 @@ static int pick_panel(int L, int batch)
     return P;
 }
 
-vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int n,
-                                 const double *x, size_t sx, const double *y, size_t sy,
-                                 const uint8_t *vis, size_t sv, double sigma,
-                                 double *value, double *g, size_t sg, double *H, int ldH, size_t sH,
-                                 int32_t *code, const int *active)
+// Scratch of the entry point that allocates nothing: the records and per-block pose sums of the
+// two-launch form for at most kStaticLandmarks landmarks over all instances of a call and
+// kStaticBlocks (instance, 256-landmark block) pairs.  One copy per GPU, held until the process ends.
+constexpr size_t kStaticLandmarks = 81920, kStaticBlocks = 4096;
+constexpr size_t kStaticRecDoubles = kStaticLandmarks * kRecFields, kStaticPartDoubles = kStaticBlocks * 28;
+static __device__ __align__(256) double scratch[kStaticRecDoubles + kStaticPartDoubles];
+// Device address of `scratch` per GPU (the array's name is a host-side stand-in, not a device address).
+constexpr int kMaxDevices = 64;
+static double *g_static_scratch[kMaxDevices];
+static std::mutex g_static_scratch_mutex;
+
+vslam_status loglik_static_scratch_init(vslam_ctx *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= kMaxDevices) return VSLAM_OK;      // beyond the table: the no-alloc entry reports it
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (g_static_scratch[ctx->device]) return VSLAM_OK;
+    double *ptr = nullptr;
+    VSLAM_HIP_TRY(ctx, hipGetSymbolAddress(reinterpret_cast<void **>(&ptr), HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(ctx, VSLAM_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the static scratch array");
+    g_static_scratch[ctx->device] = ptr;
+    return VSLAM_OK;
+}
+
+static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, int batch, int n,
+                                             const double *x, size_t sx, const double *y, size_t sy,
+                                             const uint8_t *vis, size_t sv, double sigma,
+                                             double *value, double *g, size_t sg, double *H, int ldH, size_t sH,
+                                             int32_t *code, const int *active, double *static_scratch)
 {
     if (!x || !y || !vis || !value) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null input/value pointer");
     if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L with L>=1", n);
@@ -407,17 +432,27 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
     a.lconst = -std::log(2.0 * 3.14159265358979323846264338327950288) - 2.0 * std::log(sigma);
     const int panels = (a.L + a.P - 1) / a.P;
     dim3 block(kThreads);
-    const bool two_launch = H && ldH == n && (size_t)batch * n * n * 8 >= ((size_t)32 << 20);
+    // With the static scratch every Hessian goes through the two-launch form (the one that needs scratch).
+    const bool two_launch = H && ldH == n && (static_scratch || (size_t)batch * n * n * 8 >= ((size_t)32 << 20));
     if (two_launch) {
         const int slices = (int)(((size_t)n * n * 8 + 127 + kSliceBytes - 1) / kSliceBytes) + 1;
         TermsArgs t;
         t.a = a;
         t.nblk = (a.L + kThreads - 1) / kThreads;
         const size_t rec_doubles = (size_t)batch * kRecFields * a.L, part_doubles = (size_t)batch * t.nblk * 28;
-        VSLAM_TRY(scratch_reserve(ctx, Arena::pad(rec_doubles * 8) + Arena::pad(part_doubles * 8)));
-        Arena ar(ctx->scratch);
-        t.rec = ar.take<double>(rec_doubles);
-        t.part = ar.take<double>(part_doubles);
+        if (static_scratch) {
+            if ((size_t)batch * a.L > kStaticLandmarks || (size_t)batch * t.nblk > kStaticBlocks)
+                return fail(ctx, VSLAM_ERR_CAPACITY,
+                            "point_loglik (no allocation): %d instances x %d landmarks exceed the static scratch (%zu landmarks, %zu blocks of %d)",
+                            batch, a.L, kStaticLandmarks, kStaticBlocks, kThreads);
+            t.rec = static_scratch;                      // every word the kernels read is written first: nothing to clear
+            t.part = static_scratch + kStaticRecDoubles;
+        } else {
+            VSLAM_TRY(scratch_reserve(ctx, Arena::pad(rec_doubles * 8) + Arena::pad(part_doubles * 8)));
+            Arena ar(ctx->scratch);
+            t.rec = ar.take<double>(rec_doubles);
+            t.part = ar.take<double>(part_doubles);
+        }
         const bool timed = ctx->time_kernels && ctx->tev[0];
         if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[0], ctx->stream));
         hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), block, 0, ctx->stream, cam, t);
@@ -435,6 +470,15 @@ vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int
     }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
+}
+
+vslam_status launch_point_loglik(vslam_ctx *ctx, const CamK &cam, int batch, int n,
+                                 const double *x, size_t sx, const double *y, size_t sy,
+                                 const uint8_t *vis, size_t sv, double sigma,
+                                 double *value, double *g, size_t sg, double *H, int ldH, size_t sH,
+                                 int32_t *code, const int *active)
+{
+    return launch_point_loglik_impl(ctx, cam, batch, n, x, sx, y, sy, vis, sv, sigma, value, g, sg, H, ldH, sH, code, active, nullptr);
 }
 
 }  // namespace vslam
@@ -478,6 +522,23 @@ extern "C" vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_point_loglik(ctx, k, batch, n, x, stride_x, y, stride_y, visible, stride_vis, sigma, value, g,
                                stride_g, H, ldH, stride_H, code, nullptr);
+}
+
+extern "C" vslam_status vslam_point_loglik_batch_dev_noalloc(vslam_ctx *ctx, const vslam_camera *cam, int batch, int n,
+                                                             const double *x, size_t stride_x, const double *y, size_t stride_y,
+                                                             const uint8_t *visible, size_t stride_vis, double sigma,
+                                                             double *value, double *g, size_t stride_g,
+                                                             double *H, int ldH, size_t stride_H, int32_t *code)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    CamK k;
+    VSLAM_TRY(resolve_camera(ctx, cam, &k));
+    if (H && ldH != n) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik (no allocation): ldH=%d must equal n=%d", ldH, n);
+    if (ctx->device < 0 || ctx->device >= kMaxDevices || !g_static_scratch[ctx->device])
+        return fail(ctx, VSLAM_ERR_DEVICE, "point_loglik (no allocation): no static scratch address for device %d", ctx->device);
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_point_loglik_impl(ctx, k, batch, n, x, stride_x, y, stride_y, visible, stride_vis, sigma, value, g,
+                                    stride_g, H, ldH, stride_H, code, nullptr, g_static_scratch[ctx->device]);
 }
 
 extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,

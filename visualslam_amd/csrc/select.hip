@@ -92,21 +92,21 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelArgs a)
         }
         for (;;) {                                                // resolve the chunk in feature order
             __syncthreads();
+            const int cnt = n_acc;                                // read where nobody writes it: the winner's store comes two barriers later
             if (tid == 0) first = INT_MAX;
             __syncthreads();
             if (cand) atomicMin(&first, tid);
             __syncthreads();
             const int win = first;
-            if (win == INT_MAX || n_acc >= a.max_new) break;
+            if (win == INT_MAX || cnt >= a.max_new) break;        // uniform: both values were read between barriers
             if (tid == win) {
-                const int slot = n_acc;
-                ax[slot] = fx; ay[slot] = fy;
-                if (slot < a.cap) sel[slot] = i;
-                n_acc = slot + 1;
+                ax[cnt] = fx; ay[cnt] = fy;
+                if (cnt < a.cap) sel[cnt] = i;
+                n_acc = cnt + 1;
                 cand = false;
             }
             __syncthreads();
-            if (cand && tid > win) cand = !sel_within(ax[n_acc - 1], ay[n_acc - 1], fx, fy, a.dthr);
+            if (cand && tid > win) cand = !sel_within(ax[cnt], ay[cnt], fx, fy, a.dthr);
         }
         __syncthreads();
     }
