@@ -96,6 +96,43 @@ def test_qr_tall_panels_many_workgroups(ctx, m, k):
     assert not np.tril(R, -1).any()
 
 
+def test_qr_config4_size_vs_lapack(ctx):
+    """The 6012 x 6012 re-triangularisation of the 2,000-landmark update (column blocks resident in LDS, each launch
+    applying the previous block's reflectors) against LAPACK."""
+    from visualslam_amd import api
+    rng = np.random.default_rng(6012)
+    A = rng.standard_normal((6012, 6012))
+    R = api.qr_upper(ctx, A)
+    R0 = np.linalg.qr(A, mode="r")
+    assert rel_err(R, R0) <= 1e-11
+    assert np.array_equal(np.sign(np.diag(R)), np.sign(np.diag(R0)))
+    assert not np.tril(R, -1).any()
+
+
+@pytest.mark.parametrize("m,k", [(500, 64), (3000, 200)])
+def test_qr_panels_that_leave_the_fast_path(ctx, m, k):
+    """Panels the Cholesky-QR + reconstruction path must hand to the column-by-column path: a column that nearly
+    repeats another (the Gram matrix of the panel is numerically singular), a pivot that is exactly zero (the
+    reflector sign comes from the convention, not from the data), a column that is already triangular."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(m + 7 * k)
+    A = rng.standard_normal((m, k))
+    A[:, 40] = A[:, 3] + 1e-11 * rng.standard_normal(m)       # nearly dependent inside one panel
+    A[0, 0] = 0.0                                             # zero pivot, non-zero tail
+    A[34:, 33] = 0.0                                          # zero tail below the diagonal of column 33 ... after the
+    A[:33, 33] = 0.0                                          # ... earlier reflections have nothing to mix in
+    A[33, 33] = -2.5
+    R = api.qr_upper(ctx, A)
+    R0 = orc.qr_upper(A)[:k]
+    assert rel_err(R[:k].T @ R[:k], A.T @ A) <= 1e-12
+    good = np.abs(np.diag(R0)) > 1e-6
+    assert np.array_equal(np.sign(np.diag(R)[good]), np.sign(np.diag(R0)[good]))
+    rows = np.flatnonzero(good)
+    rows = rows[rows < 40]                                    # rows before the nearly dependent column are well determined
+    assert rel_err(R[rows][:, :40], R0[rows][:, :40]) <= 1e-9
+
+
 def test_qr_tall_batched_many_workgroups(ctx):
     import torch
     from visualslam_amd import api

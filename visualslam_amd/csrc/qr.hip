@@ -20,7 +20,7 @@
 // V is read straight out of the factored panel (unit diagonal and zeros above it are synthesised by
 // the GEMM's operand loader).  One wide matrix additionally groups four panels into a 128-column
 // block whose far updates run on a side stream (see qr_outer_block).
-#include "linalg.hpp"
+#include "qr_block.hpp"
 #include <cstdlib>
 
 namespace vslam {
@@ -539,8 +539,16 @@ static bool use_outer_blocks(int rows, int cols, int batch)
     return batch == 1 && coop_rows_per(rows, batch) > 0 && cols >= 2 * OB;
 }
 
+// Columns qr_block_kernel keeps resident per launch.
+static bool use_outer_blocks(int rows, int cols, int batch);
+static int block_width(int rows, int cols, int batch)
+{
+    return use_outer_blocks(rows, cols, batch) ? QB_BW_MAX : QR_NB;
+}
+
 struct QrWs {
     double *T, *Wpart, *W2, *slots;
+    double *xbuf; unsigned *xflags;       // exchange area and flag words of qr_block_kernel
     double *Vbuf[2], *G[2], *Mo[2], *Gpart, *Wn, *Wnpart, *Wb, *Wbpart;   // outer-block path only (double-buffered per block parity)
 };
 
@@ -551,6 +559,12 @@ static void qr_carve(void *ws, int rows, int cols, int batch, QrWs *w)
     w->Wpart = ar.take<double>((size_t)batch * max_ksplit(rows, batch) * NB * (size_t)cols);
     w->W2 = ar.take<double>((size_t)batch * NB * (size_t)cols);
     w->slots = ar.take<double>((size_t)(batch > 8 ? 1 : batch) * 3 * CP_GMAX * CP_SLOT);
+    {
+        QrBlockPlan pl;
+        const bool ok = qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl);
+        w->xbuf = ar.take<double>(ok ? (size_t)batch * pl.xbuf_doubles : 1);
+        w->xflags = ar.take<unsigned>(ok ? (size_t)batch * pl.flag_words : 1);
+    }
     if (use_outer_blocks(rows, cols, batch)) {
         for (int i = 0; i < 2; ++i) {
             w->Vbuf[i] = ar.take<double>((size_t)rows * OB);
@@ -571,6 +585,11 @@ size_t qr_ws_bytes(int rows, int cols, int batch)
     size_t wpart = Arena::pad((size_t)batch * max_ksplit(rows, batch) * NB * (size_t)cols * 8);
     size_t w2 = Arena::pad((size_t)batch * NB * (size_t)cols * 8);
     size_t coop = Arena::pad((size_t)(batch > 8 ? 1 : batch) * 3 * CP_GMAX * CP_SLOT * 8);
+    {
+        QrBlockPlan pl;
+        const bool ok = qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl);
+        coop += Arena::pad((ok ? (size_t)batch * pl.xbuf_doubles : 1) * 8) + Arena::pad((ok ? (size_t)batch * pl.flag_words : 1) * 4);
+    }
     size_t big = 0;
     if (use_outer_blocks(rows, cols, batch))
         big = 2 * (Arena::pad((size_t)rows * OB * 8) + Arena::pad((size_t)OB * OB * 8) + Arena::pad((size_t)(OB / NB) * MSTRIDE * 8)) +
@@ -586,6 +605,10 @@ struct QrJob {
     size_t strideA;
     int batch, rows_per;
     unsigned tbase;
+    bool use_block;          // panels go through qr_block_kernel
+    QrBlockPlan pl;
+    unsigned launches;       // launches of qr_block_kernel so far in this factorisation
+    int ob;                  // reflectors per outer block (128, or what qr_block_kernel keeps resident)
     QrWs w;
 };
 
@@ -596,6 +619,13 @@ static vslam_status qr_factor_panel(QrJob &q, int j, int jb, double *Tdst, doubl
     const int mp = q.rows - j;
     double *P = q.A + (size_t)j * q.lda + j;
     hipStream_t s = q.ctx->stream;
+    if (q.use_block) {
+        const unsigned seq0 = 256u * q.launches++;
+        if (Vout && vzero > 0)
+            VSLAM_HIP_TRY(q.ctx, hipMemset2DAsync(Vout - vzero, (size_t)ldv * 8, 0, (size_t)vzero * 8, (size_t)jb, s));
+        return qr_block_launch(q.ctx, s, q.pl, P, q.lda, q.strideA, q.batch, mp, jb, jb, seq0, Tdst, (size_t)MSTRIDE, Vout, ldv,
+                               q.w.xbuf, q.w.xflags);
+    }
     if (q.rows_per > 0 || mp <= CP_RMAX) {
         // A panel of at most CP_RMAX rows fits one workgroup's LDS: no exchange, any batch.
         const int rows_per = (mp <= CP_RMAX) ? ((mp + 63) / 64) * 64 : q.rows_per;
@@ -662,16 +692,17 @@ static vslam_status qr_apply_outer(QrJob &q, int par, int mp0, double *C, int nc
     if (kw > 8) kw = 8;
     if (kw < 1) kw = 1;
     const size_t count = (size_t)OB * nc;
+    const int ob = q.ob;
     GemmDesc gw;                                   // Y = V^T C (K-slabs)
-    gw.M = OB; gw.N = nc; gw.K = mp0; gw.transA = true; gw.transB = false;
+    gw.M = ob; gw.N = nc; gw.K = mp0; gw.transA = true; gw.transB = false;
     gw.A = q.w.Vbuf[par]; gw.lda = mp0; gw.B = C; gw.ldb = q.lda;
     gw.C = (kw == 1) ? W : Wpart; gw.ldc = OB; gw.ksplit = kw; gw.strideSplit = count;
     VSLAM_TRY(gemm_f64_on(ctx, gw, stream));
     hipLaunchKernelGGL(qr_block_solve_kernel, dim3((nc + SOLVE_CT - 1) / SOLVE_CT, 1), dim3(256), 0, stream,
-                       (kw == 1) ? W : Wpart, count, kw, OB, (size_t)0, OB, nc, q.w.G[par], q.w.Mo[par], (size_t)0, W, OB, (size_t)0);
+                       (kw == 1) ? W : Wpart, count, kw, OB, (size_t)0, ob, nc, q.w.G[par], q.w.Mo[par], (size_t)0, W, OB, (size_t)0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     GemmDesc gu;                                   // C -= V W
-    gu.M = mp0; gu.N = nc; gu.K = OB; gu.transA = false; gu.transB = false; gu.alpha = -1.0; gu.beta = 1.0;
+    gu.M = mp0; gu.N = nc; gu.K = ob; gu.transA = false; gu.transB = false; gu.alpha = -1.0; gu.beta = 1.0;
     gu.A = q.w.Vbuf[par]; gu.lda = mp0; gu.B = W; gu.ldb = OB; gu.C = C; gu.ldc = q.lda;
     return gemm_f64_on(ctx, gu, stream);
 }
@@ -726,6 +757,50 @@ static vslam_status qr_outer_block(QrJob &q, int j0, int blk)
     return VSLAM_OK;
 }
 
+// One outer block of `ob` columns at (j0, j0) factored by ONE launch of qr_block_kernel: its panels and the
+// updates between them stay in LDS, and the launch first applies the previous block's reflectors to its own
+// columns (it starts `ob` rows higher to cover the rows of R they touch), so consecutive launches follow each
+// other on the main stream with no small kernels between them.
+// Side stream: the block's reflectors as one unit (Gram matrix + the panels' T) update everything beyond the
+// next block, overlapping the next launch; when no further resident block follows, everything beyond this one.
+// Events: [par] block factored (main -> side); [4+par] its update done (side -> main: the launch two blocks
+// later reads those columns and rewrites this parity's reflector buffers).
+static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next_resident)
+{
+    vslam_ctx *ctx = q.ctx;
+    hipStream_t s = ctx->stream, t = ctx->side;
+    const int ob = q.pl.bw, mp0 = q.rows - j0, par = blk & 1;
+    if (blk >= 2) VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[4 + par], 0));
+    const unsigned seq0 = 256u * q.launches++;
+    if (blk == 0)
+        VSLAM_TRY(qr_block_launch(ctx, s, q.pl, q.A + (size_t)j0 * q.lda + j0, q.lda, q.strideA, 1, mp0, ob, ob, seq0,
+                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf, q.w.xflags));
+    else
+        VSLAM_TRY(qr_block_launch(ctx, s, q.pl, q.A + (size_t)j0 * q.lda + (j0 - ob), q.lda, q.strideA, 1, mp0 + ob, ob, ob, seq0,
+                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf, q.w.xflags,
+                                  ob, q.w.Vbuf[par ^ 1], mp0 + ob, q.w.Mo[par ^ 1], ob / QR_NB));
+    const int first = next_resident ? j0 + 2 * ob : j0 + ob;     // first column the side stream updates
+    const int nside = q.cols - first;
+    if (nside <= 0) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->ev[par], s));
+    VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(t, ctx->ev[par], 0));
+    int ks = (mp0 + 255) / 256;
+    if (ks > 64) ks = 64;
+    GemmDesc gg;                                   // Gram slabs
+    gg.M = ob; gg.N = ob; gg.K = mp0; gg.transA = true; gg.transB = false;
+    gg.A = q.w.Vbuf[par]; gg.lda = mp0; gg.B = q.w.Vbuf[par]; gg.ldb = mp0;
+    gg.C = q.w.Gpart; gg.ldc = OB; gg.ksplit = ks; gg.strideSplit = (size_t)OB * OB;
+    if (ks == 1) gg.C = q.w.G[par];
+    VSLAM_TRY(gemm_f64_on(ctx, gg, t));
+    if (ks > 1) {
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(OB * OB / 256), dim3(256), 0, t, q.w.Gpart, (size_t)OB * OB, ks, (size_t)OB * OB, q.w.G[par]);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+    }
+    VSLAM_TRY(qr_apply_outer(q, par, mp0, q.A + (size_t)first * q.lda + j0, nside, q.w.Wb, q.w.Wbpart, t));
+    VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->ev[4 + par], t));
+    return VSLAM_OK;
+}
+
 vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
 {
     if (rows < 1 || cols < 1 || lda < rows) return fail(ctx, VSLAM_ERR_SHAPE, "qr: bad shape %dx%d ld %d", rows, cols, lda);
@@ -733,9 +808,12 @@ vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda
     QrJob q;
     q.ctx = ctx; q.A = A; q.rows = rows; q.cols = cols; q.lda = lda; q.strideA = strideA; q.batch = batch;
     q.tbase = 0; q.rows_per = coop_rows_per(rows, batch);
+    q.launches = 0; q.ob = OB;
+    q.use_block = qr_block_plan(rows, batch, block_width(rows, cols, batch), &q.pl) && !getenv("VSLAM_QR_COLUMNWISE");
     qr_carve(ws, rows, cols, batch, &q.w);
     const int kmax = rows < cols ? rows : cols;
     hipStream_t s = ctx->stream;
+    if (q.use_block) VSLAM_HIP_TRY(ctx, hipMemsetAsync(q.w.xflags, 0, (size_t)batch * q.pl.flag_words * 4, s));
     if (q.rows_per > 0) {
         const size_t words = (size_t)batch * 3 * CP_GMAX * CP_SLOT * 2;
         VSLAM_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q.w.slots), (int)CP_EMPTY32, words, s));
@@ -751,8 +829,15 @@ vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda
     if (use_outer_blocks(rows, cols, batch)) {
         VSLAM_TRY(side_stream_init(ctx));
         int blk = 0;
-        for (; j0 + OB <= kmax; j0 += OB, ++blk)
-            VSLAM_TRY(qr_outer_block(q, j0, blk));
+        const bool resident = q.use_block && q.pl.bw > QR_NB && !getenv("VSLAM_QR_PANELWISE");
+        if (resident) {
+            q.ob = q.pl.bw;
+            for (; j0 + q.ob <= kmax; j0 += q.ob, ++blk)
+                VSLAM_TRY(qr_outer_block_resident(q, j0, blk, j0 + 2 * q.ob <= kmax));
+        } else {
+            for (; j0 + OB <= kmax; j0 += OB, ++blk)
+                VSLAM_TRY(qr_outer_block(q, j0, blk));
+        }
         if (blk > 0) {                                                           // join the side stream
             VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[4], 0));
             VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[5], 0));
@@ -799,6 +884,17 @@ extern "C" vslam_status vslam_qr_upper(vslam_ctx *ctx, double *A, int rows, int 
     VSLAM_TRY(qr_upper_dev(ctx, dA, rows, cols, rows, 0, 1, qws));
     VSLAM_TRY(d2h_2d(ctx, A, (size_t)lda * 8, dA, (size_t)rows * 8, (size_t)rows * 8, cols));
     return stream_finish(ctx);
+}
+
+// Test hook (not part of the public header): copies `count` doubles from the start of the context's workspace
+// (where the last factorisation left the compact-WY T of its last panel) to the host.
+extern "C" vslam_status vslam_debug_ws_read(vslam_ctx *ctx, double *out, int count)
+{
+    if (!ctx || !out || count < 0 || (size_t)count * 8 > ctx->ws_bytes) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    VSLAM_HIP_TRY(ctx, hipMemcpy(out, ctx->ws, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return VSLAM_OK;
 }
 
 // Test hook (not part of the public header): C = alpha*op(A)*op(B) + beta*C with host pointers.
