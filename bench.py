@@ -110,8 +110,8 @@ def host_info():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--instances", type=int, default=512, help="filter instances per GPU per step")
     ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step (corner leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,6 +177,31 @@ def main():
     # results to rank 0 (outside the timed region): the only exchange a sharded batch needs
     all_vals = sharding.gather_to_root(val)
     gathered_ok = None if all_vals is None else bool(all(torch.isfinite(v).all().item() for v in all_vals) and len(all_vals) == world)
+    # ... with the payload a bank of filters hands over: posterior mean + packed upper-triangular factor per filter
+    # (a small bank per rank runs one lock-step measurement update here, outside the timed region)
+    filt_msg = None
+    try:
+        nb_f = 16
+        scs = [syn.Scene(L, sharding.instance_seed(9500, rank, i), dense_S=True) for i in range(4)]
+        f_mu = torch.tensor(np.stack([scs[i % 4].x for i in range(nb_f)]), device=dev)
+        f_S = torch.tensor(np.stack([np.ascontiguousarray(scs[i % 4].S.T) for i in range(nb_f)]), device=dev)
+        f_y = torch.tensor(np.stack([scs[i % 4].y for i in range(nb_f)]), device=dev)
+        f_v = torch.tensor(np.stack([scs[i % 4].visible for i in range(nb_f)]), device=dev)
+        f_mo, f_So = torch.empty_like(f_mu), torch.empty_like(f_S)
+        _, _, f_status = api.measurement_update_iekf_batch_dev(ctx, cam, f_mu, f_S, f_y, f_v, SIGMA, f_mo, f_So)
+        t_g = time.perf_counter()
+        msg = sharding.gather_filter_results_to_root(f_mo, f_So)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t_g
+        if msg is not None:
+            mu_all, S_all = sharding.unpack_filter_results(msg, n)
+            filt_msg = {"filters_per_rank": nb_f, "doubles_per_filter": int(msg.shape[1]), "bytes_per_rank": int(msg.shape[1]) * 8 * nb_f,
+                        "gather_ms": t_g * 1e3, "filters_on_root": int(msg.shape[0]),
+                        "own_block_round_trip_exact": bool(torch.equal(mu_all[:nb_f], f_mo) and torch.equal(S_all[:nb_f], torch.tril(f_So))),
+                        "not_positive_definite_on_rank0": int(f_status.sum())}
+        del f_mu, f_S, f_y, f_v, f_mo, f_So, msg
+    except Exception as exc:      # the headline measurement above must not be lost to a failure here
+        filt_msg = {"error": repr(exc)}
 
     # the two kernels of the call apart (outside the timed region): events inside the library, on its stream
     ctx.set_kernel_timing(True)
@@ -217,9 +242,9 @@ def main():
         units = B * L * args.steps * world
         alg = loglik_algorithmic_bytes(n, L) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = None                        # not measured in this run: replayed from the committed counter passes
         tfile = os.path.join(ROOT, "profiles", "traffic_point_loglik.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and B == 512:
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         out = {
             "metric": "landmark Jacobian updates/s", "value": units / elapsed, "unit": "landmark updates/s",
@@ -233,12 +258,15 @@ def main():
                        "parallelism": "replicated instances, no collective"},
             "roofline": {"bound": "hbm", "kernel": "loglik_terms_kernel + loglik_assemble_kernel (one point_loglik call)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "replayed from profiles/traffic_point_loglik.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "tools/run_loglik.py 512 150, FETCH doubled per the gfx950 note); not re-measured in this run",
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
                          "kernels_apart": {"loglik_terms_kernel_ms": terms_ms, "loglik_assemble_kernel_ms": assemble_ms,
                                            "assemble_alone_frac": alg / (assemble_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "events recorded by the library between its two launches; achieved/frac "
                                                    "above price the whole call (both kernels and the gap between them)"}},
             "results_gathered_to_root": gathered_ok,
+            "filter_results_gathered_to_root": filt_msg,
             "single_instance_latency_us": single_us,
             "single_instance_updates_per_s": L / (single_us * 1e-6),
             "host": host_info(),

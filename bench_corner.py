@@ -46,6 +46,21 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # keypoint lists to rank 0 (outside the timed region): counts, then the padded records (Harris lists)
+    kp_msg = None
+    try:
+        from visualslam_amd import sharding
+        t_g = time.perf_counter()
+        got = sharding.gather_keypoints_to_root(cnt[:, 0].contiguous(), out[:, 0].contiguous())
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t_g
+        if got is not None:
+            call, rall = got
+            k0 = int(call[0])
+            kp_msg = {"frames_on_root": int(call.shape[0]), "records_per_frame": int(rall.shape[1]), "bytes_per_rank": int(rall.shape[1]) * 12 * F + 4 * F,
+                      "gather_ms": t_g * 1e3, "own_block_round_trip_exact": bool(torch.equal(rall[0, :k0], out[0, 0, :k0]))}
+    except Exception as exc:
+        kp_msg = {"error": repr(exc)}
     if rank != 0:
         return None
     counts = cnt.cpu().numpy()
@@ -64,8 +79,10 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
         "mean_keypoints_per_frame": {"harris": float(counts[:, 0].mean()), "shi_tomasi": float(counts[:, 1].mean())},
         "roofline": {"bound": "hbm", "kernel": "corner_strip_kernel<3> + sort/merge/emit", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "replayed from profiles/traffic_corner.json (rocprofv3 --pmc passes of tools/run_corner.py 64); not re-measured in this run",
                      "algorithmic_bytes_per_step": alg, "device_ms_per_step": dev_ms},
         "dtype": "u8 -> int32 structure tensor -> f32 response",
+        "keypoints_gathered_to_root": kp_msg,
     }
     # FAST-9/16 (first stage of cv::ORB::detect) on the same frames: threshold 20 as the reference configures it
     fout = torch.zeros((F, cap, 3), dtype=torch.int32, device=dev)

@@ -219,3 +219,18 @@ def test_measurement_update_iekf_2000_landmarks(ctx, gcam):
     probe = rng.standard_normal((sc.n, 4))
     back = Sp.T @ (Sp @ (H1 @ probe))                       # (S^T S) H = I on random probes
     assert rel_err(back, probe) <= 1e-8
+
+
+@pytest.mark.parametrize("case", ["interior", "boundary", "indefinite"])
+def test_trs_driver_vs_dense_numpy_solve_on_the_gpu_box(case):
+    """The host driver of the eigenvalue route (trs of src/fmin.cpp:40-131 as restated in the library) against an
+    independent dense numpy solution, run with the GPU tests so that the library that is loaded here is the one checked."""
+    import ctypes as C
+    from visualslam_amd import _lib
+    import test_host_logic_cpu as H
+    lib = _lib.lib()
+    lib.vslam_debug_sym_eig.restype = None
+    lib.vslam_debug_sym_eig.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vslam_debug_trs.restype = C.c_int
+    lib.vslam_debug_trs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    H.test_trs_host_vs_dense_numpy_solve(lib, case, 162)

@@ -97,6 +97,52 @@ def test_trs_host_vs_oracle(L, case):
         assert model(p) <= model(q) + 1e-9 * (1 + abs(model(q)))
 
 
+def _trs_dense(H, g, D):
+    """The trust-region subproblem min g'p + p'Hp/2, |p| <= D solved without the eigenbasis formulas of the driver:
+    the multiplier by bisection on |(H + lam I)^-1 g| = D with dense solves (numpy only, nothing shared with the
+    library or the oracle)."""
+    n = g.size
+    w = np.linalg.eigvalsh(H)
+    if w[0] > 0:
+        p = -np.linalg.solve(H, g)
+        if np.linalg.norm(p) <= D:
+            return p
+    lo = max(0.0, -w[0]) + 1e-14 * max(1.0, abs(w[0]))
+    hi = lo + 1.0
+    norm_at = lambda lam: np.linalg.norm(np.linalg.solve(H + lam * np.eye(n), g))
+    while norm_at(hi) > D:
+        hi = lo + 2.0 * (hi - lo)
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if norm_at(mid) > D:
+            lo = mid
+        else:
+            hi = mid
+    return -np.linalg.solve(H + hi * np.eye(n), g)
+
+
+@pytest.mark.parametrize("n", [12, 162])
+@pytest.mark.parametrize("case", ["interior", "boundary", "indefinite"])
+def test_trs_host_vs_dense_numpy_solve(L, case, n):
+    """The step of the driver's trs against an independent dense solution of the same subproblem."""
+    rng = np.random.default_rng(11 + n)
+    A = rng.standard_normal((n, n))
+    H = A @ A.T / n + 0.5 * np.eye(n)
+    g = rng.standard_normal(n)
+    D = 100.0
+    if case == "boundary":
+        D = 0.05
+    if case == "indefinite":
+        H = H - 3.0 * np.eye(n)
+        D = 0.7
+    Q, v = _eig(L, H)
+    p = np.zeros(n)
+    L.vslam_debug_trs(Q.ctypes.data, v.ctypes.data, g.ctypes.data, n, D, p.ctypes.data)
+    p0 = _trs_dense(H, g, D)
+    assert np.max(np.abs(p - p0)) <= 1e-6 * max(1.0, np.max(np.abs(p0)))      # the driver stops its multiplier iteration at sqrt(eps)
+    assert abs(np.linalg.norm(p) - (np.linalg.norm(p0))) <= 1e-6 * D
+
+
 def test_chi2inv_normcdf_host(L):
     from oracle import pyoracle as orc
     from visualslam_amd import api

@@ -141,6 +141,24 @@ def test_remove_landmark_general_square_factor(ctx):
     assert rel_err(S1.T @ S1, (S.T @ S)[np.ix_(keep, keep)]) < 1e-12
 
 
+def test_remove_landmark_reference_scenarios(ctx):
+    """test/src/deleteLandmarks.cpp:11-156: a state of two landmarks (mu = 1..18, S = diag(1..18)); removing landmark 1
+    leaves 15 states, removing landmark 1 then landmark 0 leaves 12 -- the dimensions that test pins, and with this
+    diagonal factor also the values (the remaining entries, untouched)."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    mu = np.arange(1.0, 19.0)
+    S = np.diag(np.arange(1.0, 19.0))
+    mu1, S1 = api.remove_landmark(ctx, mu, S, 1)
+    assert mu1.shape == (15,) and S1.shape == (15, 15)
+    assert np.array_equal(mu1, np.arange(1.0, 16.0)) and np.array_equal(S1, np.diag(np.arange(1.0, 16.0)))
+    o_mu, o_S = orc.remove_landmark(mu, S, 1)
+    assert o_mu.shape == (15,) and o_S.shape == (15, 15) and np.array_equal(o_S, S1)
+    mu2, S2 = api.remove_landmark(ctx, mu1, S1, 0)
+    assert mu2.shape == (12,) and S2.shape == (12, 12)
+    assert np.array_equal(mu2, np.arange(1.0, 13.0)) and np.array_equal(S2, np.diag(np.arange(1.0, 13.0)))
+
+
 def test_remove_landmark_errors(ctx):
     from visualslam_amd import api
     with pytest.raises(api.VslamError):

@@ -68,6 +68,41 @@ def test_rotation_kats():
     assert np.allclose(orc.rot2rpy(orc.rpy2rot(th)), th, rtol=1e-13)
 
 
+def _approx(got, want):
+    """Catch2 v2's default Approx: |got - want| < eps * (scale + |want|), eps = 100 * float epsilon, scale = 0 ...
+    with the margin the reference's tests rely on for expected zeros taken as 1e-12 (they print -0 / 0)."""
+    return abs(got - want) <= 1.1920929e-5 * abs(want) + 1e-12
+
+
+def test_rotation_kats_all_reference_scenarios():
+    """Every scenario of test/src/rot2rpy.cpp:6-176 and test/src/rpy2rot.cpp:12-407 (known answers extracted by
+    tests/golden/make_rotation_kats.py): axis rotations at 0, 0.1 and 5 pi / 3, rpy2rot at [1, 2, 3], rot2rpy on the
+    identity, on the three axis rotations by 0.5 rad and as the inverse mapping on a general rotation."""
+    K = json.load(open(os.path.join(GOLDEN, "rotation_kats.json")))
+    assert len(K["rot2rpy"]) == 5 and len(K["rpy2rot"]) == 10
+    for c in K["rpy2rot"]:
+        kind = c["title"].split(":")[0]
+        if kind in ("rotx", "roty", "rotz"):
+            R = orc.rot(kind[-1], c["scalars"]["x"])
+        else:
+            R = orc.rpy2rot(c["matrices"]["Theta"])
+        assert len(c["checks"]["R"]) == 9
+        for i, j, want in c["checks"]["R"]:
+            assert _approx(R[i, j], want), (c["title"], i, j, R[i, j], want)
+    for c in K["rot2rpy"]:
+        R = np.array(c["matrices"]["R"]).reshape(3, 3)
+        th = orc.rot2rpy(R)
+        assert th.shape == (3,)
+        if c["checks"]:
+            for i, _, want in c["checks"]["Theta"]:
+                assert _approx(th[i], want), (c["title"], i, th[i], want)
+        else:                                                    # "rot2rpy is an inverse mapping": rpy2rot(rot2rpy(R)) == R
+            Ract = orc.rpy2rot(th)
+            for i in range(3):
+                for j in range(3):
+                    assert abs(Ract[i, j] - R[i, j]) <= 1.1920929e-5 * abs(R[i, j]) + 1e-9, (i, j, Ract[i, j], R[i, j])
+
+
 # ---- symbolic golden vectors ---------------------------------------------
 def test_world_to_pixel_golden(ocam):
     G = json.load(open(os.path.join(GOLDEN, "world_to_pixel.json")))

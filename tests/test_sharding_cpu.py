@@ -61,6 +61,36 @@ def _worker(rank, world, port, total, out):
         assert (rooted is None) == (rank != 0)
         if rank == 0:
             assert [r.tolist() for r in rooted] == [[float(q)] * 3 for q in range(world)]
+        # the two result messages: keypoint lists (counts + padded records) and filter posteriors (mean + packed
+        # factor), checked on the root for content and for the order in which the ranks' blocks are reassembled
+        F, cap, kmax = 3, 40, 16
+        cnt = torch.tensor([5 + rank, 0, 40], dtype=torch.int32)
+        rec = (torch.arange(F * cap * 3, dtype=torch.int32).reshape(F, cap, 3) + 100000 * (rank + 1))
+        kp = sharding.gather_keypoints_to_root(cnt, rec, k_max=kmax)
+        B, n = 2, 5
+        mu = torch.arange(B * n, dtype=torch.float64).reshape(B, n) + 1000.0 * rank
+        Su = torch.triu(torch.arange(1, n * n + 1, dtype=torch.float64).reshape(n, n)) + 0.5 * rank     # upper triangular S
+        Sp = torch.stack([Su.T.contiguous() + b for b in range(B)])                                      # column-major per instance
+        Sp = Sp * (torch.tril(torch.ones(n, n)))[None]                                                   # keep the stored triangle only
+        fl = sharding.gather_filter_results_to_root(mu, Sp)
+        assert (kp is None) == (rank != 0) and (fl is None) == (rank != 0)
+        if rank == 0:
+            call, rall = kp
+            assert call.tolist() == [5, 0, 16, 6, 0, 16] and rall.shape == (world * F, kmax, 3)
+            for q in range(world):
+                want = torch.arange(F * cap * 3, dtype=torch.int32).reshape(F, cap, 3) + 100000 * (q + 1)
+                for i in range(F):
+                    k = int(call[q * F + i])
+                    assert torch.equal(rall[q * F + i, :k], want[i, :k]) and not rall[q * F + i, k:].any()
+            assert fl.shape == (world * B, n + n * (n + 1) // 2)
+            mu_all, S_all = sharding.unpack_filter_results(fl, n)
+            for q in range(world):
+                for b in range(B):
+                    assert torch.equal(mu_all[q * B + b], torch.arange(b * n, (b + 1) * n, dtype=torch.float64) + 1000.0 * q)
+                    Sq = (torch.triu(torch.arange(1, n * n + 1, dtype=torch.float64).reshape(n, n)) + 0.5 * q).T + b
+                    assert torch.equal(S_all[q * B + b], Sq * torch.tril(torch.ones(n, n)))
+            # packed by columns: first entries are S(0,0), S(0,1), S(1,1), S(0,2) ...
+            assert fl[0, n:n + 4].tolist() == [Su[0, 0].item(), Su[0, 1].item(), Su[1, 1].item(), Su[0, 2].item()]
         dist.barrier()
         if rank == 0:
             flat = torch.cat([g[g >= 0] for g in got])

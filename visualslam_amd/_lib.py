@@ -91,6 +91,7 @@ def _declare(L):
         "vslam_ctx_synchronize": [_vp],
         "vslam_ctx_set_trs_solver": [_vp, C.c_int],
         "vslam_ctx_last_trs_route": [_vp],
+        "vslam_ctx_last_update_profile": [_vp, _vp],
         "vslam_ctx_set_kernel_timing": [_vp, C.c_int],
         "vslam_ctx_last_point_loglik_times": [_vp, _vp, _vp],
         "vslam_camera_from_xml": [C.c_char_p, C.POINTER(Camera)],

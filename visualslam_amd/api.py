@@ -36,11 +36,18 @@ class Context:
         self.device = device
 
     def set_trs_solver(self, solver):
-        """TRS_EIG (default: the reference's host eigenvalue route) or TRS_CHOLESKY (device route, eigenvalue fallback)."""
+        """TRS_CHOLESKY (default: device route, eigenvalue fallback) or TRS_EIG (the reference's host eigenvalue route)."""
         check(self._L.vslam_ctx_set_trs_solver(self.ptr, int(solver)), self.ptr)
 
     def last_trs_route(self):
         return int(self._L.vslam_ctx_last_trs_route(self.ptr))
+
+    def last_update_profile(self):
+        """Wall-clock split of the last device-route measurement update (dict, ms and counts)."""
+        out = np.zeros(8)
+        check(self._L.vslam_ctx_last_update_profile(self.ptr, out.ctypes.data), self.ptr)
+        return {"cost_evaluations_ms": out[0], "trust_region_ms": out[1], "posterior_factor_ms": out[2], "device_part_ms": out[3],
+                "cost_evaluations": int(out[4]), "factorisations": int(out[5]), "iterations": int(out[6])}
 
     def synchronize(self):
         check(self._L.vslam_ctx_synchronize(self.ptr), self.ptr)

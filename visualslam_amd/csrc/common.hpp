@@ -34,7 +34,9 @@ struct vslam_ctx {
                                  // marks of the chained triangular solve (value = chain_epoch of the call)
     int chain_epoch = 0;
     int *flags_host = nullptr;   // pinned mirror read by stream_finish
-    int trs_solver = 0;          // VSLAM_TRS_EIG (default) / VSLAM_TRS_CHOLESKY
+    int trs_solver = 1;          // VSLAM_TRS_CHOLESKY (default: device route, eigenvalue route when the Hessian is indefinite) / VSLAM_TRS_EIG
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last measurement update on the device route: ms in cost evaluations, trust-region
+                                 // factorisations + solves, posterior factor, whole call; counts of evaluations and factorisations
     int trs_last = -1;           // route the last measurement update took (-1: none yet)
     bool time_kernels = false;   // measurement aid: events around the two kernels of the batched log-likelihood
     hipEvent_t tev[3] = {nullptr, nullptr, nullptr};

@@ -145,6 +145,14 @@ extern "C" int vslam_debug_trs(const double *Q, const double *v, const double *g
 
 extern "C" int vslam_ctx_last_trs_route(const vslam_ctx *ctx) { return ctx ? ctx->trs_last : -1; }
 
+extern "C" vslam_status vslam_ctx_last_update_profile(vslam_ctx *ctx, double *out8)
+{
+    if (!ctx || !out8) return VSLAM_ERR_ARG;
+    if (ctx->trs_last != VSLAM_TRS_CHOLESKY) return fail(ctx, VSLAM_ERR_ARG, "last_update_profile: the last measurement update did not run on the device route");
+    for (int i = 0; i < 8; ++i) out8[i] = ctx->prof[i];
+    return VSLAM_OK;
+}
+
 extern "C" vslam_status vslam_iekf_post_sqrt(vslam_ctx *ctx, const double *Q, const double *v, int n, double *S_out);
 
 extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *cam,

@@ -17,6 +17,8 @@
 // to the signs of its rows, which there depend on the eigensolver's choice of eigenvector signs.
 #include "linalg.hpp"
 
+#include <chrono>
+
 #include <cmath>
 #include <limits>
 
@@ -247,10 +249,18 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     newton_carve(ws, n, &w);
     const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
     const int nb = (n + 255) / 256;
-    int evals = 0;
+    int evals = 0, factorisations = 0;
     double hd[4];
     int hinfo = 0;
     *status_out = 0;
+    // Wall-clock split of the call for the bench's breakdown; every phase below ends at a stream synchronisation
+    // (the cost value, the dot products and the final copies are read on the host), so the split costs nothing.
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    const clk::time_point t_call = clk::now();
+    clk::time_point t_phase = t_call;
+    double ms_cost = 0.0, ms_trs = 0.0;
+    auto phase_to = [&](double &acc) { acc += ms_since(t_phase); t_phase = clk::now(); };
 
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
         DotArgs d;
@@ -267,6 +277,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
         if (lam != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(nb), dim3(256), 0, s, w.U, n, n, lam);
         VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+        ++factorisations;
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.gcur, w.t));
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p));
         hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, -1.0, w.p, 0.0, (const double *)nullptr, w.p, n);
@@ -279,6 +290,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         VSLAM_TRY(d2h(ctx, f, c->vals + 2, 8));
         VSLAM_TRY(stream_sync(ctx));
         ++evals;
+        phase_to(ms_cost);
         return VSLAM_OK;
     };
     auto accept = [&]() -> vslam_status {                    // current iterate := the point just evaluated
@@ -324,6 +336,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
         const double pg = hd[0], pHp = hd[1];
         pn = std::sqrt(hd[2]);
+        phase_to(ms_trs);
         if (std::fabs(-pg) < 2 * eps) { ret = 0; break; }
         VSLAM_TRY(eval_at(w.xn, &fn));
         const double dm = -pg - 0.5 * pHp, rho = (f - fn) / dm;
@@ -346,6 +359,8 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     VSLAM_TRY(stream_finish(ctx));
     if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
     *fmin_code = ret; *iters = it; *evals_out = evals;
+    ctx->prof[0] = ms_cost; ctx->prof[1] = ms_trs; ctx->prof[2] = ms_since(t_phase); ctx->prof[3] = ms_since(t_call);
+    ctx->prof[4] = evals; ctx->prof[5] = factorisations; ctx->prof[6] = it;
     return VSLAM_OK;
 }
 

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
         double *Tg = a.T + (size_t)b * a.strideT + (size_t)p * QR_MSTRIDE;
 
         // the panel as it stands goes back to memory: the column-by-column path restarts from it
-        if (p > 0) {
+        if (p > 0 || a.roff > 0) {
             for (int c = wave; c < nb; c += QB_T / 64)
                 for (int i = lane; i < nr; i += 64) A[(size_t)(c0 + c) * a.lda + r0 + i] = Bk[(size_t)(c0 + c) * ldr + i];
         }
