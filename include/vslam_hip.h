@@ -409,6 +409,47 @@ vslam_status vslam_fast9_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, i
                                           int frames, int threshold, int nonmax, int max_features,
                                           vslam_feature *out, int cap, int32_t *count);
 
+/* ---- ORB keypoints: cv::ORB::create(nfeatures, 1.2f, 8, 75, 0, 2, HARRIS_SCORE, 75, 20)->detect as called by
+ * detectAndDrawORB, src/imagefeatures.cpp:73-87 (keypoints only: orientation and the rBRIEF descriptors need OpenCV's
+ * learned sampling pattern, which is neither in the reference nor reproducible here).  OpenCV's sources are not
+ * part of the reference: the chain below restates the published algorithm and the CPU oracle defines the contract
+ * ("parity unpinned").  Per pyramid level: FAST-9/16 at fast_threshold with non-maximum suppression; corners closer
+ * than edge_threshold to a side dropped; the 2 n strongest by FAST score kept, every tie of the last one included;
+ * at those corners only, the Harris measure of a harris_block^2 window of Sobel-like integer gradients,
+ * (a b - c^2 - k (a + b)^2) (1 / (4 block 255))^4 in float; the n best kept, ties included.  Levels: level l has
+ * scale s_l = scale_factor^l, size round(w / s_l) x round(h / s_l), resized from level l-1 (bilinear, integer
+ * arithmetic in 1/2048 pixel: this library's own definition, not OpenCV's INTER_LINEAR_EXACT); the feature budget
+ * n_l follows the geometric series of cv::ORB. */
+#define VSLAM_ORB_MAX_LEVELS 16
+typedef struct {
+    int32_t nfeatures;        /* 10000 at src/SLAM.cpp:349 */
+    float scale_factor;       /* 1.2 */
+    int32_t nlevels;          /* 8 */
+    int32_t edge_threshold;   /* 75 */
+    int32_t fast_threshold;   /* 20 */
+    int32_t harris_block;     /* 7 */
+    float harris_k;           /* 0.04 */
+    int32_t reserved_;
+} vslam_orb_params;
+/* cv::KeyPoint as far as detection fills it: position in base-image pixels (level position times the level's
+ * scale, in float), response, octave. */
+typedef struct { float x, y, response; int32_t octave; } vslam_orb_keypoint;
+/* Sizes, feature budgets and scales of the pyramid levels (host; arrays of params->nlevels entries). */
+vslam_status vslam_orb_level_plan(const vslam_orb_params *params, int w, int h, int32_t *level_w, int32_t *level_h,
+                                  int32_t *level_features, float *level_scale);
+/* One level for a batch of device-resident frames: keypoints in level coordinates, sorted by Harris response
+ * (ties by y then x); count[f] = -1 when a frame has more than 65536 corners or ties at a cut beyond 16384. */
+vslam_status vslam_orb_detect_level_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                              int frames, int nfeatures, int fast_threshold, int edge_threshold, int harris_block,
+                                              float harris_k, vslam_feature *out, int cap, int32_t *count);
+/* The level-to-level resize on its own (device pointers). */
+vslam_status vslam_resize_bilinear_dev(vslam_ctx *ctx, const uint8_t *src, int sw, int sh, int sstride,
+                                       uint8_t *dst, int dw, int dh, int dstride);
+/* All levels of one host image: keypoints level by level (level 0 first), within a level sorted by response;
+ * level_counts (optional) receives the number per level. */
+vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *params,
+                              vslam_orb_keypoint *out, int cap, int32_t *count, int32_t *level_counts);
+
 #ifdef __cplusplus
 }
 #endif

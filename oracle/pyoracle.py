@@ -387,6 +387,51 @@ def fast9_detect(gray, threshold=20, nonmax=True, max_features=16384, cap=None):
     return out[:n].copy()
 
 
+def orb_detect_level(gray, nfeatures, fast_threshold=20, edge=75, block=7, harris_k=0.04):
+    """Keypoints of one ORB level (cv::ORB::detect, reference src/imagefeatures.cpp:73-87; parity unpinned), level coordinates."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    cap = max(4 * nfeatures + 1024, 1024)
+    out = np.zeros(cap, dtype=FEATURE_DTYPE)
+    n = _lib.orc_orb_detect_level(_b(gray), w, h, w, int(nfeatures), int(fast_threshold), int(edge), int(block),
+                                  C.c_float(harris_k), out.ctypes.data_as(C.c_void_p), cap)
+    assert n >= 0
+    return out[:n].copy()
+
+
+def resize_bilinear(gray, dw, dh):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    sh, sw = gray.shape
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    _lib.orc_resize_bilinear(_b(gray), sw, sh, sw, _b(dst), dw, dh, dw)
+    return dst
+
+
+def orb_level_plan(w, h, nfeatures=10000, scale_factor=1.2, nlevels=8):
+    lw, lh, lf = (np.zeros(nlevels, dtype=np.int32) for _ in range(3))
+    ls = np.zeros(nlevels, dtype=np.float32)
+    _lib.orc_orb_level_plan(int(nfeatures), C.c_float(scale_factor), int(nlevels), int(w), int(h),
+                            lw.ctypes.data_as(C.c_void_p), lh.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                            ls.ctypes.data_as(C.c_void_p))
+    return lw, lh, lf, ls
+
+
+def orb_detect(gray, nfeatures=10000, scale_factor=1.2, nlevels=8, edge=75, fast_threshold=20, block=7, harris_k=0.04):
+    """All levels: list over levels of (x float32, y float32, response float32) arrays in base-image pixels."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    lw, lh, lf, ls = orb_level_plan(w, h, nfeatures, scale_factor, nlevels)
+    out, img = [], gray
+    for l in range(nlevels):
+        if l > 0:
+            img = resize_bilinear(img, int(lw[l]), int(lh[l]))
+        if lw[l] < 2 * edge + 1 or lh[l] < 2 * edge + 1:
+            out.append(np.zeros(0, dtype=FEATURE_DTYPE))
+            continue
+        out.append(orb_detect_level(img, int(lf[l]), fast_threshold, edge, block, harris_k))
+    return out, ls
+
+
 def normcdf(z):
     return float(_lib.orc_normcdf(float(z)))
 

@@ -1452,6 +1452,112 @@ int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshol
 }
 
 
+/* ---- ORB keypoints of one pyramid level: cv::ORB::detect as configured at src/imagefeatures.cpp:73-87
+ * (HARRIS_SCORE, edgeThreshold 75, fastThreshold 20).  PARITY UNPINNED: OpenCV is not in the reference tree, no
+ * reference test covers it (test/src/matcher.cpp is commented out); this restates the published algorithm of
+ * OpenCV 4.5's ORB detector and is the contract the GPU path is held to:
+ *   1. FAST-9/16 at fast_threshold with non-maximum suppression (orc_fast9_detect);
+ *   2. KeyPointsFilter::runByImageBorder: keep edge <= x < w - edge, edge <= y < h - edge;
+ *   3. KeyPointsFilter::retainBest(2 n) on the FAST score: the 2 n strongest and every tie of the last of them;
+ *   4. HarrisResponses at those corners: over the block x block window centred on the corner,
+ *        Ix = 2 (p[+1] - p[-1]) + (p[-s+1] - p[-s-1]) + (p[s+1] - p[s-1]),  Iy alike with rows and columns swapped,
+ *        a = sum Ix^2, b = sum Iy^2, c = sum Ix Iy in int,
+ *        response = ((float)a b - (float)c c - k ((float)a + b) ((float)a + b)) * scale^4, scale = 1 / (4 block 255),
+ *      every float operation rounded once, scale^4 formed as ((scale scale) scale) scale;
+ *   5. retainBest(n) on the response, ties included.
+ * Output sorted by response descending, ties by y then x.  Returns the count, or -1 when cap is too small. */
+static int retain_best_sorted(orc_feature *f, int cnt, int n)
+{
+    if (n <= 0) return 0;
+    if (cnt <= n) return cnt;
+    float cut = f[n - 1].score;
+    int k = n;
+    while (k < cnt && f[k].score == cut) ++k;
+    return k;
+}
+
+int orc_orb_detect_level(const uint8_t *gray, int w, int h, int stride, int nfeatures, int fast_threshold, int edge,
+                         int block, float harris_k, orc_feature *out, int cap)
+{
+    int capc = w * h / 4 + 16;
+    orc_feature *cand = (orc_feature *)malloc((size_t)capc * sizeof(orc_feature));
+    int cnt = orc_fast9_detect(gray, w, h, stride, fast_threshold, 1, capc, cand, capc);
+    int m = 0;
+    for (int i = 0; i < cnt; ++i)
+        if (cand[i].x >= edge && cand[i].x < w - edge && cand[i].y >= edge && cand[i].y < h - edge) cand[m++] = cand[i];
+    m = retain_best_sorted(cand, m, 2 * nfeatures);
+    volatile float scale = 1.0f / (4.0f * (float)block * 255.0f);
+    volatile float s2 = scale * scale;
+    volatile float s3 = s2 * scale;
+    volatile float s4 = s3 * scale;
+    const int r = block / 2;
+    for (int i = 0; i < m; ++i) {
+        int a = 0, b = 0, c = 0;
+        for (int dy = -r; dy < block - r; ++dy)
+            for (int dx = -r; dx < block - r; ++dx) {
+                const uint8_t *p = gray + (size_t)(cand[i].y + dy) * stride + cand[i].x + dx;
+                int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-stride + 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[stride - 1]);
+                int Iy = ((int)p[stride] - (int)p[-stride]) * 2 + ((int)p[stride - 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[-stride + 1]);
+                a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+            }
+        volatile float fa = (float)a, fb = (float)b, fc = (float)c;
+        volatile float ab = fa * fb, cc = fc * fc, tr = fa + fb;
+        volatile float ktr = harris_k * tr;
+        volatile float ktr2 = ktr * tr;
+        volatile float d1 = ab - cc;
+        volatile float d2 = d1 - ktr2;
+        volatile float resp = d2 * s4;
+        cand[i].score = resp;
+    }
+    qsort(cand, (size_t)m, sizeof(orc_feature), feat_cmp);
+    m = retain_best_sorted(cand, m, nfeatures);
+    int ret = m;
+    if (m > cap) ret = -1;
+    else memcpy(out, cand, (size_t)m * sizeof(orc_feature));
+    free(cand);
+    return ret;
+}
+
+/* The level-to-level resize of the pyramid as this build defines it (OpenCV's INTER_LINEAR_EXACT arithmetic is not in
+ * the reference tree: PARITY UNPINNED): bilinear at source position (x + 1/2) sw / dw - 1/2, held in units of 1/2048
+ * pixel by integer arithmetic, clamped to the image; weights in 1/2048, result rounded to nearest. */
+void orc_resize_bilinear(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride)
+{
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            long long X = ((long long)(2 * x + 1) * sw * 1024) / dw - 1024, Y = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
+            if (X < 0) X = 0;
+            if (X > (long long)(sw - 1) * 2048) X = (long long)(sw - 1) * 2048;
+            if (Y < 0) Y = 0;
+            if (Y > (long long)(sh - 1) * 2048) Y = (long long)(sh - 1) * 2048;
+            int x0 = (int)(X >> 11), y0 = (int)(Y >> 11), ax = (int)(X & 2047), ay = (int)(Y & 2047);
+            int x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+            unsigned p00 = src[(size_t)y0 * sstride + x0], p01 = src[(size_t)y0 * sstride + x1];
+            unsigned p10 = src[(size_t)y1 * sstride + x0], p11 = src[(size_t)y1 * sstride + x1];
+            unsigned v = p00 * (2048 - ax) * (2048 - ay) + p01 * ax * (2048 - ay) + p10 * (2048 - ax) * ay + p11 * ax * ay;
+            dst[(size_t)y * dstride + x] = (uint8_t)((v + (1u << 21)) >> 22);
+        }
+}
+
+/* Level sizes, feature budgets and scales of cv::ORB's pyramid (firstLevel 0): scale_l = (float)pow(scaleFactor, l),
+ * size = cvRound(cols / scale_l) x cvRound(rows / scale_l), budgets by the geometric series with factor 1 / scaleFactor,
+ * the last level taking the remainder.  PARITY UNPINNED (restated from the published OpenCV 4.5 algorithm). */
+void orc_orb_level_plan(int nfeatures, float scale_factor, int nlevels, int w, int h, int *lw, int *lh, int *lf, float *ls)
+{
+    float factor = (float)(1.0 / (double)scale_factor);
+    float desired = (float)nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        float sc = (float)pow((double)scale_factor, (double)l);
+        ls[l] = sc;
+        lw[l] = (int)nearbyint((double)((float)w / sc));
+        lh[l] = (int)nearbyint((double)((float)h / sc));
+        if (l < nlevels - 1) { lf[l] = (int)nearbyint((double)desired); sum += lf[l]; desired *= factor; }
+        else lf[l] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    }
+}
+
+
 /* ---- caller-side selection of new landmarks, src/SLAM.cpp:449-472 with pixelDistance, src/SLAM.cpp:746-760
  * (pinned by test/src/pixelDistance.cpp).  The loop index of pixelDistance is uninitialised in the reference
  * (`for(int i; ...)`); it is defined as 0 here.  Arithmetic as there: cv::Point2f difference, float products and

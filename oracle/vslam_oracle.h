@@ -198,6 +198,10 @@ int orc_select_new_landmarks(const orc_feature *feats, int K, const float *landm
 int orc_fast9_strength(const uint8_t *gray, int w, int h, int stride, int x, int y);
 int orc_fast9_detect(const uint8_t *gray, int w, int h, int stride, int threshold, int nonmax, int max_features,
                      orc_feature *out, int cap);
+int orc_orb_detect_level(const uint8_t *gray, int w, int h, int stride, int nfeatures, int fast_threshold, int edge,
+                         int block, float harris_k, orc_feature *out, int cap);
+void orc_resize_bilinear(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride);
+void orc_orb_level_plan(int nfeatures, float scale_factor, int nlevels, int w, int h, int *lw, int *lh, int *lf, float *ls);
 
 #ifdef __cplusplus
 }

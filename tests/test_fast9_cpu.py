@@ -64,3 +64,14 @@ def test_hand_checkable_square():
     img[10, 10] = 210
     k = orc.fast9_detect(img, 20, nonmax=True)
     assert [(int(a), int(b), float(c)) for a, b, c in k] == [(10, 10, 159.0)]
+
+
+def test_orb_level_plan_matches_published_series():
+    """Level sizes and feature budgets of cv::ORB's pyramid for the reference's parameters (10 000 features, 1.2, 8 levels
+    on 1920 x 1080): the oracle's restatement and the library's host function agree, budgets sum to nfeatures."""
+    from visualslam_amd import api
+    lw, lh, lf, ls = orc.orb_level_plan(1920, 1080)
+    assert lw.tolist() == [1920, 1600, 1333, 1111, 926, 772, 643, 536] and lh.tolist() == [1080, 900, 750, 625, 521, 434, 362, 301]
+    assert lf.sum() == 10000 and lf[0] == 2172
+    glw, glh, glf, gls = api.orb_level_plan(api.orb_params(), 1920, 1080)
+    assert np.array_equal(glw, lw) and np.array_equal(glh, lh) and np.array_equal(glf, lf) and np.array_equal(gls, ls)

@@ -133,6 +133,36 @@ def test_qr_panels_that_leave_the_fast_path(ctx, m, k):
     assert rel_err(R[rows][:, :40], R0[rows][:, :40]) <= 1e-9
 
 
+def test_two_contexts_factor_large_matrices_at_once(ctx):
+    """Two contexts on their own streams each queue a 4100 x 4100 factorisation without waiting for the other.  The
+    workgroups of such a factorisation wait for one another; the library queues the two one after the other on the
+    GPU instead of letting them compete for compute units."""
+    import torch
+    from visualslam_amd import api
+    n = 4100
+    rng = np.random.default_rng(41)
+    As = [rng.standard_normal((n, n)) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = [api.Context(0, stream=s_.cuda_stream) for s_ in streams]
+    ts = [torch.tensor(np.ascontiguousarray(A_.T), device="cuda:0") for A_ in As]       # column-major n x n
+    torch.cuda.synchronize()
+    for rep in range(2):                                     # second round: workspaces exist, launches go back to back
+        for c_, t_ in zip(ctxs, ts):
+            api.qr_upper_batch_dev(c_, t_, n, n, n, 1, n * n)
+        if rep == 0:
+            torch.cuda.synchronize()
+            for A_, t_ in zip(As, ts):
+                t_.copy_(torch.tensor(np.ascontiguousarray(A_.T)))
+            torch.cuda.synchronize()
+    for c_ in ctxs:
+        c_.synchronize()
+    for A_, t_ in zip(As, ts):
+        R0 = np.linalg.qr(A_, mode="r")
+        assert rel_err(t_.cpu().numpy().T, R0) <= 1e-11
+    for c_ in ctxs:
+        c_.close()
+
+
 def test_qr_tall_batched_many_workgroups(ctx):
     import torch
     from visualslam_amd import api

@@ -31,6 +31,11 @@ class SelectParams(C.Structure):
                 ("max_new", C.c_int32), ("reserved", C.c_int32)]
 
 
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32), ("edge_threshold", C.c_int32),
+                ("fast_threshold", C.c_int32), ("harris_block", C.c_int32), ("harris_k", C.c_float), ("reserved_", C.c_int32)]
+
+
 class Feature(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("score", C.c_float)]
 
@@ -136,6 +141,10 @@ def _declare(L):
         "vslam_initialize_landmarks_batch_dev": [_vp, C.POINTER(Camera), _vp, _vp, _i, _i, _vp, _i, _d, _d, _vp, _vp],
         "vslam_fast9_detect": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
         "vslam_fast9_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _vp, _i, _vp],
+        "vslam_orb_level_plan": [C.POINTER(OrbParams), _i, _i, _vp, _vp, _vp, _vp],
+        "vslam_orb_detect_level_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _i, C.c_float, _vp, _i, _vp],
+        "vslam_resize_bilinear_dev": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i],
+        "vslam_orb_detect": [_vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _vp, _i, _vp, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
     }
     for name, args in sig.items():

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, CornerParams, SelectParams, VslamError, check  # noqa: F401
+from ._lib import Camera, CornerParams, OrbParams, SelectParams, VslamError, check  # noqa: F401
 
 FEATURE_DTYPE = np.dtype([("x", np.int32), ("y", np.int32), ("score", np.float32)])
 LAYOUT_COMPAT, LAYOUT_STRICT = 0, 1
@@ -432,6 +432,47 @@ def fast9_detect(ctx, gray, threshold=20, nonmax=True, max_features=16384, cap=N
     check(ctx._L.vslam_fast9_detect(ctx.ptr, _p(gray), w, h, stride, int(threshold), int(bool(nonmax)), int(max_features),
                                     _p(out), cap, _p(cnt)), ctx.ptr)
     return out[:int(cnt[0])].copy()
+
+
+ORB_KEYPOINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("response", np.float32), ("octave", np.int32)])
+
+
+def orb_params(nfeatures=10000, scale_factor=1.2, nlevels=8, edge_threshold=75, fast_threshold=20, harris_block=7, harris_k=0.04):
+    """cv::ORB::create(nfeatures, 1.2f, 8, 75, 0, 2, HARRIS_SCORE, 75, 20) as at reference src/imagefeatures.cpp:73-82."""
+    return OrbParams(int(nfeatures), float(scale_factor), int(nlevels), int(edge_threshold), int(fast_threshold), int(harris_block),
+                     float(harris_k), 0)
+
+
+def orb_level_plan(params, w, h):
+    nl = params.nlevels
+    lw, lh, lf = (np.zeros(nl, dtype=np.int32) for _ in range(3))
+    ls = np.zeros(nl, dtype=np.float32)
+    check(_lib.lib().vslam_orb_level_plan(C.byref(params), int(w), int(h), _p(lw), _p(lh), _p(lf), _p(ls)))
+    return lw, lh, lf, ls
+
+
+def orb_detect(ctx, gray, params=None, cap=32768):
+    """ORB keypoints of all pyramid levels (no orientation, no descriptors): (keypoints, per-level counts)."""
+    params = orb_params() if params is None else params
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    out = np.zeros(cap, dtype=ORB_KEYPOINT_DTYPE)
+    cnt = np.zeros(1, dtype=np.int32)
+    lev = np.zeros(params.nlevels, dtype=np.int32)
+    check(ctx._L.vslam_orb_detect(ctx.ptr, _p(gray), w, h, w, C.byref(params), _p(out), cap, _p(cnt), _p(lev)), ctx.ptr)
+    return out[:int(cnt[0])].copy(), lev
+
+
+def orb_detect_level_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, nfeatures, out, cap, count,
+                               fast_threshold=20, edge_threshold=75, harris_block=7, harris_k=0.04):
+    check(ctx._L.vslam_orb_detect_level_batch_dev(ctx.ptr, _tp(gray), w, h, stride, stride_frame, frames, int(nfeatures), int(fast_threshold),
+                                                  int(edge_threshold), int(harris_block), float(harris_k), _tp(out), cap, _tp(count)), ctx.ptr)
+
+
+def resize_bilinear_dev(ctx, src, dst):
+    """src (sh, sw) and dst (dh, dw) uint8 torch tensors on the GPU, rows contiguous."""
+    check(ctx._L.vslam_resize_bilinear_dev(ctx.ptr, _tp(src), src.shape[1], src.shape[0], src.stride(0), _tp(dst), dst.shape[1],
+                                           dst.shape[0], dst.stride(0)), ctx.ptr)
 
 
 def corner_response(ctx, gray, params):

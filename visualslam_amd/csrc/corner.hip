@@ -28,6 +28,9 @@
 // keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
 // unpacks the leading keys into Feature records.
 #include "common.hpp"
+
+#include <cmath>
+#include <vector>
 #include <cstdlib>
 
 namespace vslam {
@@ -620,6 +623,7 @@ constexpr int FT_W = 64, FT_H = 32, FT_IW = FT_W + 8, FT_IH = FT_H + 8, FT_SW = 
 struct FastArgs {
     const uint8_t *gray; size_t stride_frame;
     int w, h, stride, threshold, nonmax, tiles_x, frames;
+    int border = 0;        // corners closer than this to an image side are dropped after suppression (ORB's edge threshold)
     uint64_t *cand;        // [frame][2][CAND_CAP], list 0 used
     int32_t *cand_count;   // [frame][2]
 };
@@ -705,6 +709,7 @@ __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
     for (int ly = tid >> 6; ly < FT_H; ly += FT_T / 64) {
         const int lx = tid & 63, px = x0 + lx, py = y0 + ly;
         if (px >= w || py >= h) continue;
+        if (px < a.border || py < a.border || px >= w - a.border || py >= h - a.border) continue;
         const int s = st[ly + 1][lx + 1];
         if (s == 0) continue;
         bool keep = true;
@@ -730,6 +735,150 @@ __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
     uint64_t *dst = a.cand + (size_t)frame * 2 * CAND_CAP;
     for (int i = tid; i < nstaged; i += FT_T)
         if (gbase + i < CAND_CAP) dst[gbase + i] = stage[i];
+}
+
+static size_t detect_ws_bytes(int frames);
+
+// ---- keypoints of one ORB pyramid level, cv::ORB::detect as the reference configures it (src/imagefeatures.cpp:73-87:
+// HARRIS_SCORE, edgeThreshold 75, fastThreshold 20).  OpenCV's sources are not part of the reference; the chain restated
+// here (and in the CPU oracle, which defines the contract) is the published one: FAST-9/16 with non-maximum suppression,
+// corners closer than the edge threshold to a side dropped, the 2 n strongest by FAST score kept (with every tie of the
+// last one), the Harris measure of a 7 x 7 block of Sobel-like integer gradients evaluated AT those corners only
+// (k = 0.04, scaled by (1 / (4 * 7 * 255))^4), the n best by that measure kept (again with ties).
+// Candidate list 0 of the frame holds the FAST keys, list 1 the Harris keys; both are sorted by the kernels above.
+
+// One workgroup per frame: how many leading keys of the sorted list survive "retain the n best, ties included".
+// kept[frame] = that count, or -1 when the ties run past the part of the list that is sorted (SORT_S keys).
+__global__ __launch_bounds__(1024) void orb_cut_kernel(const uint64_t *cand, const int32_t *cand_count, int list_of_frame, int n_keep, int32_t *kept)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const size_t list = (size_t)f * 2 + list_of_frame;
+    const int raw = cand_count[list];
+    const uint64_t *keys = cand + list * CAND_CAP;
+    const int avail = min(raw, SORT_S);                       // sorted prefix
+    if (raw <= n_keep) { if (tid == 0) kept[f] = raw > CAND_CAP ? -1 : raw; return; }
+    if (n_keep <= 0) { if (tid == 0) kept[f] = 0; return; }
+    if (n_keep > avail) { if (tid == 0) kept[f] = -1; return; }
+    const uint32_t cut = (uint32_t)(keys[n_keep - 1] >> 32);  // score bits of the n-th best
+    for (int i = n_keep - 1 + tid; i < avail; i += 1024) {
+        const bool in = (uint32_t)(keys[i] >> 32) == cut;
+        const bool next_in = (i + 1 < avail) && (uint32_t)(keys[i + 1] >> 32) == cut;
+        if (in && !next_in) kept[f] = (i + 1 == avail && raw > avail) ? -1 : i + 1;     // exactly one thread finds the end of the ties
+    }
+}
+
+struct OrbHarrisArgs {
+    const uint8_t *gray; size_t stride_frame;
+    int w, h, stride, block;
+    float k, scale4;
+    uint64_t *cand; int32_t *cand_count; const int32_t *kept;
+};
+
+// Thread i of a frame: Harris measure at the i-th kept FAST corner -> key i of list 1.
+__global__ __launch_bounds__(256) void orb_harris_kernel(OrbHarrisArgs a)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int kept = a.kept[f];
+    if (i == 0) a.cand_count[(size_t)f * 2 + 1] = kept < 0 ? 0 : kept;
+    if (i >= kept) return;
+    vslam_feature ft;
+    unpack_key(a.cand[(size_t)f * 2 * CAND_CAP + i], &ft);
+    const uint8_t *gray = a.gray + (size_t)f * a.stride_frame;
+    const int r = a.block / 2, st = a.stride;
+    int sa = 0, sb = 0, sc = 0;
+    for (int dy = -r; dy < a.block - r; ++dy) {
+        const uint8_t *p = gray + (size_t)(ft.y + dy) * st + ft.x - r;
+        for (int dx = 0; dx < a.block; ++dx, ++p) {
+            const int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-st + 1] - (int)p[-st - 1]) + ((int)p[st + 1] - (int)p[st - 1]);
+            const int Iy = ((int)p[st] - (int)p[-st]) * 2 + ((int)p[st - 1] - (int)p[-st - 1]) + ((int)p[st + 1] - (int)p[-st + 1]);
+            sa += Ix * Ix; sb += Iy * Iy; sc += Ix * Iy;
+        }
+    }
+    const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
+    const float tr = __fadd_rn(fa, fb);
+    const float resp = __fmul_rn(__fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(a.k, tr), tr)), a.scale4);
+    a.cand[((size_t)f * 2 + 1) * CAND_CAP + i] = make_key(resp, ft.x, ft.y);
+}
+
+__global__ void orb_emit_kernel(const uint64_t *cand, const int32_t *kept, int cap, vslam_feature *out, int32_t *count)
+{
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = kept[f];
+    if (i == 0) count[f] = k;
+    if (i >= k || i >= cap) return;
+    vslam_feature ft;
+    unpack_key(cand[((size_t)f * 2 + 1) * CAND_CAP + i], &ft);
+    out[(size_t)f * cap + i] = ft;
+}
+
+// dst(x, y) of the bilinear resize used between pyramid levels: source position (x + 1/2) sw / dw - 1/2 in units of
+// 1/2048 pixel (integer arithmetic throughout, so the CPU oracle and this kernel agree bit for bit), clamped to the image.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    long long X = ((long long)(2 * x + 1) * sw * 1024) / dw - 1024, Y = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
+    X = X < 0 ? 0 : (X > (long long)(sw - 1) * 2048 ? (long long)(sw - 1) * 2048 : X);
+    Y = Y < 0 ? 0 : (Y > (long long)(sh - 1) * 2048 ? (long long)(sh - 1) * 2048 : Y);
+    const int x0 = (int)(X >> 11), y0 = (int)(Y >> 11), ax = (int)(X & 2047), ay = (int)(Y & 2047);
+    const int x1 = min(x0 + 1, sw - 1), y1 = min(y0 + 1, sh - 1);
+    const unsigned p00 = src[(size_t)y0 * sstride + x0], p01 = src[(size_t)y0 * sstride + x1];
+    const unsigned p10 = src[(size_t)y1 * sstride + x0], p11 = src[(size_t)y1 * sstride + x1];
+    const unsigned v = p00 * (2048 - ax) * (2048 - ay) + p01 * ax * (2048 - ay) + p10 * (2048 - ax) * ay + p11 * ax * ay;
+    dst[(size_t)y * dstride + x] = (uint8_t)((v + (1u << 21)) >> 22);
+}
+
+static size_t orb_ws_bytes(int frames) { return detect_ws_bytes(frames) + Arena::pad((size_t)frames * 2 * 4); }
+
+static vslam_status launch_orb_level(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame, int frames,
+                                     int nfeatures, int fast_threshold, int edge, int block, float harris_k,
+                                     vslam_feature *out, int cap, int32_t *count, void *ws)
+{
+    Arena ar(ws);
+    FastArgs a;
+    a.gray = gray; a.stride_frame = stride_frame; a.w = w; a.h = h; a.stride = stride; a.threshold = fast_threshold; a.nonmax = 1;
+    a.border = edge;
+    a.cand = ar.take<uint64_t>((size_t)frames * 2 * CAND_CAP);
+    a.cand_count = ar.take<int32_t>((size_t)frames * 2);
+    int32_t *kept = ar.take<int32_t>((size_t)frames * 2);           // [0..frames): after the FAST cut, [frames..): after the Harris cut
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(a.cand_count, 0, (size_t)frames * 2 * 4, s));
+    a.tiles_x = (w + FT_W - 1) / FT_W; a.frames = frames;
+    const size_t tiles = (size_t)a.tiles_x * ((h + FT_H - 1) / FT_H) * frames;
+    if (tiles > 0x7fffffffu) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: too many tiles for one launch");
+    hipLaunchKernelGGL(fast9_tile_kernel, dim3((unsigned)tiles), dim3(FT_T), 0, s, a);
+    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 1);
+    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
+        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, step, 1);
+    hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 0, 2 * nfeatures, kept);
+    OrbHarrisArgs ha;
+    ha.gray = gray; ha.stride_frame = stride_frame; ha.w = w; ha.h = h; ha.stride = stride; ha.block = block; ha.k = harris_k;
+    {
+        volatile float sc = 1.0f / (4.0f * (float)block * 255.0f);   // scale * scale * scale * scale, left to right, one rounding each
+        volatile float s2 = sc * sc;
+        volatile float s3 = s2 * sc;
+        volatile float s4 = s3 * sc;
+        ha.scale4 = s4;
+    }
+    ha.cand = a.cand; ha.cand_count = a.cand_count; ha.kept = kept;
+    hipLaunchKernelGGL(orb_harris_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
+    hipLaunchKernelGGL(sort_chunk_kernel, dim3(1, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 2);
+    hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 1, nfeatures, kept + frames);
+    const int lim = cap < SORT_S ? cap : SORT_S;
+    hipLaunchKernelGGL(orb_emit_kernel, dim3((lim + 255) / 256, frames), dim3(256), 0, s, a.cand, kept + frames, cap, out, count);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+static vslam_status check_orb_level(vslam_ctx *ctx, int w, int h, int stride, int nfeatures, int fast_threshold, int edge, int block)
+{
+    if (block < 3 || block > 15 || !(block & 1)) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: Harris block %d must be odd in [3,15]", block);
+    if (edge < block / 2 + 2) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: edge threshold %d below the Harris block's reach %d", edge, block / 2 + 2);
+    if (w < 2 * edge + 1 || h < 2 * edge + 1 || stride < w) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect: image %dx%d (stride %d) inside an edge of %d is empty", w, h, stride, edge);
+    if (w > 65535 || h > 65535) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: image side exceeds 65535");
+    if (fast_threshold < 0 || fast_threshold > 254) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: FAST threshold %d outside [0,254]", fast_threshold);
+    if (nfeatures < 0 || 2 * nfeatures > SORT_S) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: %d features per level exceed %d", nfeatures, SORT_S / 2);
+    return VSLAM_OK;
 }
 
 static size_t tile_lds_bytes(int bs)
@@ -986,6 +1135,128 @@ extern "C" vslam_status vslam_fast9_detect(vslam_ctx *ctx, const uint8_t *gray, 
     if (hc < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: more than %d corners; raise the threshold", CAND_CAP);
     *count = hc;
     if (hc > 0) VSLAM_HIP_TRY(ctx, hipMemcpy(out, dout, (size_t)hc * sizeof(vslam_feature), hipMemcpyDeviceToHost));
+    return VSLAM_OK;
+}
+
+// ---- ORB keypoint detection (no orientation, no descriptors) ----
+extern "C" vslam_status vslam_orb_detect_level_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                                         int frames, int nfeatures, int fast_threshold, int edge_threshold, int harris_block,
+                                                         float harris_k, vslam_feature *out, int cap, int32_t *count)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: null pointer or cap < 1");
+    if (frames < 1 || frames > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect: frames=%d out of range", frames);
+    VSLAM_TRY(check_orb_level(ctx, w, h, stride, nfeatures, fast_threshold, edge_threshold, harris_block));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    VSLAM_TRY(ws_reserve(ctx, orb_ws_bytes(frames)));
+    return launch_orb_level(ctx, gray, w, h, stride, stride_frame, frames, nfeatures, fast_threshold, edge_threshold, harris_block, harris_k,
+                            out, cap, count, ctx->ws);
+}
+
+extern "C" vslam_status vslam_resize_bilinear_dev(vslam_ctx *ctx, const uint8_t *src, int sw, int sh, int sstride,
+                                                  uint8_t *dst, int dw, int dh, int dstride)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!src || !dst) return fail(ctx, VSLAM_ERR_ARG, "resize: null pointer");
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw || dstride < dw || sw > 65535 || sh > 65535 || dw > 65535 || dh > 65535)
+        return fail(ctx, VSLAM_ERR_SHAPE, "resize: %dx%d (stride %d) -> %dx%d (stride %d)", sw, sh, sstride, dw, dh, dstride);
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, ctx->stream, src, sw, sh, sstride, dst, dw, dh, dstride);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// cvRound: to nearest, ties to even
+static int round_half_even(double v) { return (int)std::nearbyint(v); }
+
+extern "C" vslam_status vslam_orb_level_plan(const vslam_orb_params *p, int w, int h, int32_t *level_w, int32_t *level_h,
+                                             int32_t *level_features, float *level_scale)
+{
+    if (!p || !level_w || !level_h || !level_features || !level_scale) return VSLAM_ERR_ARG;
+    if (p->nlevels < 1 || p->nlevels > VSLAM_ORB_MAX_LEVELS || !(p->scale_factor > 1.0f) || p->nfeatures < 0 || w < 1 || h < 1) return VSLAM_ERR_ARG;
+    const float factor = (float)(1.0 / (double)p->scale_factor);
+    float desired = (float)p->nfeatures * (1.0f - factor) / (1.0f - (float)std::pow((double)factor, (double)p->nlevels));
+    int sum = 0;
+    for (int l = 0; l < p->nlevels; ++l) {
+        const float sc = (float)std::pow((double)p->scale_factor, (double)l);
+        level_scale[l] = sc;
+        level_w[l] = round_half_even((double)((float)w / sc));
+        level_h[l] = round_half_even((double)((float)h / sc));
+        if (l < p->nlevels - 1) {
+            level_features[l] = round_half_even((double)desired);
+            sum += level_features[l];
+            desired *= factor;
+        } else {
+            level_features[l] = p->nfeatures - sum > 0 ? p->nfeatures - sum : 0;
+        }
+    }
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *p,
+                                         vslam_orb_keypoint *out, int cap, int32_t *count, int32_t *level_counts)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !p || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: null pointer or cap < 1");
+    int32_t lw[VSLAM_ORB_MAX_LEVELS], lh[VSLAM_ORB_MAX_LEVELS], lf[VSLAM_ORB_MAX_LEVELS];
+    float ls[VSLAM_ORB_MAX_LEVELS];
+    if (vslam_orb_level_plan(p, w, h, lw, lh, lf, ls) != VSLAM_OK) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: bad pyramid parameters");
+    if (stride < w) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect: stride %d < width %d", stride, w);
+    int nl = p->nlevels;
+    while (nl > 0 && (lw[nl - 1] < 2 * p->edge_threshold + 1 || lh[nl - 1] < 2 * p->edge_threshold + 1)) --nl;   // levels with nothing inside the edge
+    for (int l = 0; l < nl; ++l) VSLAM_TRY(check_orb_level(ctx, lw[l], lh[l], lw[l], lf[l], p->fast_threshold, p->edge_threshold, p->harris_block));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    size_t pyr = 0;
+    for (int l = 0; l < nl; ++l) pyr += Arena::pad((size_t)lw[l] * lh[l]);
+    const size_t feat_bytes = (size_t)SORT_S * sizeof(vslam_feature);
+    VSLAM_TRY(ws_reserve(ctx, orb_ws_bytes(1) + Arena::pad((size_t)stride * h) + pyr + (size_t)nl * Arena::pad(feat_bytes) + Arena::pad(64)));
+    Arena ar(ctx->ws);
+    void *dws = ar.take<char>(orb_ws_bytes(1));
+    uint8_t *dbase = ar.take<uint8_t>((size_t)stride * h);
+    uint8_t *dlev[VSLAM_ORB_MAX_LEVELS];
+    vslam_feature *dfeat[VSLAM_ORB_MAX_LEVELS];
+    for (int l = 0; l < nl; ++l) dlev[l] = ar.take<uint8_t>((size_t)lw[l] * lh[l]);
+    for (int l = 0; l < nl; ++l) dfeat[l] = ar.take<vslam_feature>(SORT_S);
+    int32_t *dcount = ar.take<int32_t>(16);
+    VSLAM_TRY(h2d(ctx, dbase, gray, (size_t)stride * h));
+    for (int l = 0; l < nl; ++l) {
+        // level l is resized from level l-1 (level 0 is the image itself)
+        const uint8_t *img = dbase;
+        int iw = w, ih = h, is = stride;
+        if (l > 0) {
+            const uint8_t *prev = l == 1 ? dbase : dlev[l - 1];
+            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lw[l - 1];
+            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l]), dim3(256), 0, ctx->stream, prev, pw, ph, ps, dlev[l], lw[l], lh[l], lw[l]);
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lw[l];
+        }
+        VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, 0, 1, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
+                                   dfeat[l], SORT_S, dcount + l, dws));
+    }
+    int32_t hc[16] = {0};
+    VSLAM_TRY(d2h(ctx, hc, dcount, sizeof(int32_t) * 16));
+    VSLAM_TRY(stream_sync(ctx));
+    int total = 0;
+    std::vector<vslam_feature> tmp;
+    for (int l = 0; l < p->nlevels; ++l) {
+        const int k = l < nl ? hc[l] : 0;
+        if (k < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: level %d has more candidates (or ties at the cut) than %d", l, SORT_S);
+        if (level_counts) level_counts[l] = k;
+        if (k == 0) continue;
+        tmp.resize((size_t)k);
+        VSLAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), dfeat[l], (size_t)k * sizeof(vslam_feature), hipMemcpyDeviceToHost));
+        for (int i = 0; i < k; ++i) {
+            if (total == cap) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: more than %d keypoints", cap);
+            vslam_orb_keypoint kp;
+            kp.x = l == 0 ? (float)tmp[(size_t)i].x : (float)tmp[(size_t)i].x * ls[l];      // pt *= scale, float
+            kp.y = l == 0 ? (float)tmp[(size_t)i].y : (float)tmp[(size_t)i].y * ls[l];
+            kp.response = tmp[(size_t)i].score; kp.octave = l;
+            out[total++] = kp;
+        }
+    }
+    *count = total;
     return VSLAM_OK;
 }
 

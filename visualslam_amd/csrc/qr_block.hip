@@ -827,6 +827,14 @@ vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPl
     a.xbuf = xbuf; a.xstride = pl.xbuf_doubles; a.flags = flags; a.fstride = pl.flag_words; a.cmax = pl.cmax;
     a.err = ctx->flags;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&qr_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    if (G > 1) {
+        // the workgroups of a matrix wait for one another: all of them must be resident together
+        int per_cu = 0, cus = 0;
+        VSLAM_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qr_block_kernel, QB_T, pl.lds_bytes));
+        VSLAM_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if (per_cu < 1 || G * batch > per_cu * cus)
+            return fail(ctx, VSLAM_ERR_CAPACITY, "qr block: %d workgroups that wait for one another, but only %d x %d fit on the device", G * batch, per_cu, cus);
+    }
     hipLaunchKernelGGL(qr_block_kernel, dim3(G, batch), dim3(QB_T), pl.lds_bytes, stream, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
