@@ -213,6 +213,28 @@ def test_affine_kats_on_gpu(ctx):
         assert np.allclose(R[:2], np.array(Syy), rtol=1e-10, atol=1e-12)
 
 
+def test_qr_bank_of_tall_matrices(ctx):
+    """A bank of [S C^T; SR]-sized matrices (762 x 300, the predicted measurement density of 150 landmarks): two
+    workgroups per matrix, the bank cut into launches whose workgroups are all resident together."""
+    import torch
+    from visualslam_amd import api
+    rng = np.random.default_rng(23)
+    B, m, k = 130, 762, 300
+    A = rng.standard_normal((B, k, m))
+    A[7, 5, :] = 0.0                                          # instance 7: a zero column
+    t = torch.tensor(A, device="cuda:0")
+    tctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    api.qr_upper_batch_dev(tctx, t, m, k, m, B, m * k)
+    tctx.synchronize()
+    out = t.cpu().numpy()
+    from oracle import pyoracle as orc
+    for b in (0, 1, 7, 64, 119, 120, 129):
+        R0 = orc.qr_upper(A[b].T)[:k] if b == 7 else np.linalg.qr(A[b].T, mode="r")
+        assert rel_err(out[b].T[:k], R0) <= 1e-11
+        assert not np.tril(out[b].T, -1).any()
+    tctx.close()
+
+
 def test_qr_batched_dev(ctx):
     import torch
     from visualslam_amd import api

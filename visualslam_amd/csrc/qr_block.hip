@@ -400,6 +400,7 @@ __device__ __forceinline__ void qb_xtz_tile(const double *Bk, int ldr, int r0, i
     const int a = 16 * ta + (lane & 15), zc = 16 * tb + (lane & 15), kr = lane >> 4;
     double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
     if (16 * ta < nb && 16 * tb < zn) {
+        double4_t ac[4] = {acc, acc, acc, acc};                 // four chains: a dependent fp64 MFMA waits for the one before it
         // Branch-free operand reads: every LDS address is valid (columns clamped; rows up to the next multiple of
         // 16, zero beyond the matrix), masks are applied to the values.  Sixteen rows per trip: the eight reads
         // of a trip are issued before its four MFMAs.
@@ -419,8 +420,10 @@ __device__ __forceinline__ void qb_xtz_tile(const double *Bk, int ldr, int r0, i
                 zv[u] = (zok && i >= lo) ? zv[u] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u], zv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) ac[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u], zv[u], ac[u], 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) st_sc1(dst + (16 * ta + 4 * r + kr) * 32 + zc, acc[r]);
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
             // W = Vp^T C: 32 x bwc, wave w owns column tiles 2w and 2w+1 of each 64-column half
             for (int half = 0; half < (a.bwc + 63) / 64; ++half) {
                 const int zc0 = 64 * half + 32 * (wave >> 1) + 16 * (wave & 1);       // 16 columns
-                double4_t acc0 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+                double4_t acc0 = (double4_t){0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
                 if (zc0 < a.bwc) {
                     for (int k0 = 0; k0 < rows_pad; k0 += 8) {
                         double xv[2][2], zv[2];
@@ -482,12 +485,13 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                             xv[u][1] = in ? Vp[(size_t)(16 + l15) * a.ldvp + i] : 0.0;
                             zv[u] = (in && zc0 + l15 < a.bwc) ? Bk[(size_t)(zc0 + l15) * ldr + i] : 0.0;
                         }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][0], zv[u], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][1], zv[u], acc1, 0, 0, 0);
-                        }
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[0][0], zv[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[0][1], zv[0], acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[1][0], zv[1], acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[1][1], zv[1], acc3, 0, 0, 0);
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc0[r] += acc2[r]; acc1[r] += acc3[r]; }
                 }
                 // chunk ch = zc0 / 32 holds W[a][c] at ch * 1024 + a * 32 + (c - 32 ch)
                 double *dst = x.mine + 1024 * (zc0 >> 5) + (zc0 & 31) + l15;
@@ -519,17 +523,21 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                     double vq[8];
 #pragma unroll
                     for (int q8 = 0; q8 < 8; ++q8) vq[q8] = (i < nr) ? Vp[(size_t)(4 * q8 + kr) * a.ldvp + i] : 0.0;
+                    double4_t u[2][2];
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) { u[cb][0] = (double4_t){0.0, 0.0, 0.0, 0.0}; u[cb][1] = u[cb][0]; }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            u[cb][q8 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(M1[(4 * q8 + kr) * QB_LDM + 16 * cb + l15], vq[q8], u[cb][q8 & 1], 0, 0, 0);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         if (16 * cb >= zn) continue;
-                        double4_t u = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int q8 = 0; q8 < 8; ++q8)
-                            u = __builtin_amdgcn_mfma_f64_16x16x4f64(M1[(4 * q8 + kr) * QB_LDM + 16 * cb + l15], vq[q8], u, 0, 0, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int zc = 16 * cb + 4 * r + kr;
-                            if (zc < zn && i < nr) Bk[(size_t)(z0 + zc) * ldr + i] -= u[r];
+                            if (zc < zn && i < nr) Bk[(size_t)(z0 + zc) * ldr + i] -= u[cb][0][r] + u[cb][1][r];
                         }
                     }
                 }
@@ -749,18 +757,24 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                 const int t_lo = lo >> 4, t_hi = (nr + 15) >> 4;
                 for (int rt = t_lo + wave; rt < t_hi; rt += QB_T / 64) {
                     const int i = 16 * rt + l15;
+                    double yv[8];
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8) yv[q8] = qb_yv(Bk, ldr, rb, c0, nb, i, 4 * q8 + kr);
+                    double4_t u[2][2];
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) { u[cb][0] = (double4_t){0.0, 0.0, 0.0, 0.0}; u[cb][1] = u[cb][0]; }
+#pragma unroll
+                    for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            u[cb][q8 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(M1[(4 * q8 + kr) * QB_LDM + 16 * cb + l15], yv[q8], u[cb][q8 & 1], 0, 0, 0);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         if (16 * cb >= zn) continue;
-                        double4_t u = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int k0 = 0; k0 < 32; k0 += 4)
-                            u = __builtin_amdgcn_mfma_f64_16x16x4f64(M1[(k0 + kr) * QB_LDM + 16 * cb + l15],
-                                                                     qb_yv(Bk, ldr, rb, c0, nb, i, k0 + kr), u, 0, 0, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int zc = 16 * cb + 4 * r + kr;
-                            if (zc < zn && i < nr) Bk[(size_t)(z0 + zc) * ldr + i] -= u[r];
+                            if (zc < zn && i < nr) Bk[(size_t)(z0 + zc) * ldr + i] -= u[cb][0][r] + u[cb][1][r];
                         }
                     }
                 }
@@ -783,14 +797,19 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
 
 bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
 {
-    if (rows < 1 || batch < 1 || batch > 8) return false;
-    const int gcap = 240 / batch;                          // workgroups per matrix that are certainly resident together
+    if (rows < 1 || batch < 1) return false;
+    const int gcap = batch <= 8 ? 240 / batch : 240;       // workgroups per matrix that are certainly resident together
     int bw = bw_want < 32 ? 32 : (bw_want > QB_BW_MAX ? QB_BW_MAX : (bw_want & ~31));
+    if (batch > 8) bw = 32;                                // banks: one panel per launch, as few workgroups per matrix as LDS allows
     for (; bw >= 32; bw -= 32) {
         // rows per workgroup: a multiple of 32, as small as keeps the workgroup count within 64 (or the cap) ...
         int gmax = gcap < 64 ? gcap : 64;
         int rp = 128;
-        if ((rows + rp - 1) / rp > gmax) rp = ((rows + gmax - 1) / gmax + 31) & ~31;
+        if (batch > 8) {
+            const int g = (rows + 511) / 512;              // 512 rows of a 32-column panel fill a workgroup's LDS
+            rp = ((rows + g - 1) / g + 31) & ~31;
+            if (rp < 128) rp = 128;
+        } else if ((rows + rp - 1) / rp > gmax) rp = ((rows + gmax - 1) / gmax + 31) & ~31;
         size_t lds = ((size_t)bw * (rp + 2) + QB_SMALL_DOUBLES) * 8;
         if (lds > QB_LDS_MAX && bw == 32 && gcap > 64) {
             // ... very tall matrices: up to the cap, one panel at a time
@@ -801,6 +820,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
         }
         if (lds > QB_LDS_MAX) continue;
         p->bw = bw; p->rows_per = rp; p->ldr = rp + 2; p->G = (rows + rp - 1) / rp;
+        if (p->G > 240) continue;
         p->cmax = bw > 32 ? 32 * bw : 1024;                    // W of one panel of reflectors against every resident column
         p->lds_bytes = lds < ((size_t)96 << 10) ? ((size_t)96 << 10) : lds;     // one workgroup per compute unit
         p->xbuf_doubles = (size_t)(p->G + 1) * p->cmax + 1024;
@@ -816,26 +836,36 @@ vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPl
 {
     if (bwc > pl.bw || nfac > bwc || nfac > mp || nfac < 1) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d columns (%d to factor) in a block of %d", bwc, nfac, pl.bw);
     const int G = (mp + pl.rows_per - 1) / pl.rows_per;
-    if (G > pl.G || G * batch > 240) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d workgroups per matrix exceed the plan (%d)", G, pl.G);
-    QbArgs a;
-    a.A = A; a.lda = lda; a.strideA = strideA; a.mp = mp; a.bwc = bwc; a.nfac = nfac;
-    a.rows_per = pl.rows_per; a.G = G; a.ldr = pl.ldr; a.bw = pl.bw; a.seq0 = seq0;
-    a.T = T; a.strideT = strideT; a.V = V; a.ldv = ldv;
-    a.roff = roff; a.Vprev = Vprev; a.ldvp = ldvp; a.Tprev = Tprev; a.prev_np = prev_np;
+    if (G > pl.G || G > 240) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d workgroups per matrix exceed the plan (%d)", G, pl.G);
     if (roff < 0 || roff % 32 != 0 || (roff > 0 && (!Vprev || !Tprev || batch != 1 || nfac > mp - roff)))
         return fail(ctx, VSLAM_ERR_SHAPE, "qr block: inconsistent previous-block arguments");
-    a.xbuf = xbuf; a.xstride = pl.xbuf_doubles; a.flags = flags; a.fstride = pl.flag_words; a.cmax = pl.cmax;
-    a.err = ctx->flags;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&qr_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    // The workgroups of a matrix wait for one another, so all workgroups of a launch must be resident together: a bank
+    // is cut into launches of at most 240 workgroups (they follow one another on the stream).
+    int per_launch = batch;
     if (G > 1) {
-        // the workgroups of a matrix wait for one another: all of them must be resident together
         int per_cu = 0, cus = 0;
         VSLAM_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qr_block_kernel, QB_T, pl.lds_bytes));
         VSLAM_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        if (per_cu < 1 || G * batch > per_cu * cus)
-            return fail(ctx, VSLAM_ERR_CAPACITY, "qr block: %d workgroups that wait for one another, but only %d x %d fit on the device", G * batch, per_cu, cus);
+        int room = per_cu * cus;
+        if (room > 240) room = 240;
+        if (per_cu < 1 || G > room)
+            return fail(ctx, VSLAM_ERR_CAPACITY, "qr block: %d workgroups that wait for one another, but only %d x %d fit on the device", G, per_cu, cus);
+        per_launch = room / G;
     }
-    hipLaunchKernelGGL(qr_block_kernel, dim3(G, batch), dim3(QB_T), pl.lds_bytes, stream, a);
+    if (per_launch > 65535) per_launch = 65535;
+    for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const int nb_ = batch - b0 < per_launch ? batch - b0 : per_launch;
+        QbArgs a;
+        a.A = A + (size_t)b0 * strideA; a.lda = lda; a.strideA = strideA; a.mp = mp; a.bwc = bwc; a.nfac = nfac;
+        a.rows_per = pl.rows_per; a.G = G; a.ldr = pl.ldr; a.bw = pl.bw; a.seq0 = seq0;
+        a.T = T + (size_t)b0 * strideT; a.strideT = strideT; a.V = V; a.ldv = ldv;
+        a.roff = roff; a.Vprev = Vprev; a.ldvp = ldvp; a.Tprev = Tprev; a.prev_np = prev_np;
+        a.xbuf = xbuf + (size_t)b0 * pl.xbuf_doubles; a.xstride = pl.xbuf_doubles;
+        a.flags = flags + (size_t)b0 * pl.flag_words; a.fstride = pl.flag_words; a.cmax = pl.cmax;
+        a.err = ctx->flags;
+        hipLaunchKernelGGL(qr_block_kernel, dim3(G, nb_), dim3(QB_T), pl.lds_bytes, stream, a);
+    }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
