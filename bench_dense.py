@@ -184,6 +184,32 @@ def run_dense_leg(ctx, dev, stream):
     e1.record(stream)
     torch.cuda.synchronize()
     frame["initialize_50_landmarks_n462_ms"] = e0.elapsed_time(e1) / 20
+    # the bundle measurement model on its own: dense C (2L x n) and SR (2L x 2L) are write-only outputs
+    bundle = {}
+    for Lb in (150, 2000):
+        sb = syn.Scene(Lb, 40 + Lb, dense_S=False)
+        nb_, mb_ = 12 + 3 * Lb, 2 * Lb
+        bx = torch.tensor(sb.x, device=dev)
+        bh = torch.zeros(mb_, dtype=torch.float64, device=dev)
+        bC = torch.zeros(mb_ * nb_, dtype=torch.float64, device=dev)
+        bS = torch.zeros(mb_ * mb_, dtype=torch.float64, device=dev)
+        bcode = torch.zeros(Lb, dtype=torch.int32, device=dev)
+        api.bundle_measure_dev(ctx, cam, bx, bh, bS, bC, bcode)
+        torch.cuda.synchronize()
+        reps = 50
+        e0.record(stream)
+        for _ in range(reps):
+            api.bundle_measure_dev(ctx, cam, bx, bh, bS, bC, bcode)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        nbytes = 16.0 * Lb * nb_ + 32.0 * Lb * Lb          # C and SR written once
+        gbs = nbytes / (us * 1e-6) / 1e9
+        bundle["L%d" % Lb] = {"us": us, "algorithmic_bytes": nbytes,
+                              "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                           "traffic": None}}
+        del bx, bh, bC, bS, bcode
+    frame["bundle_measure_dev"] = bundle
     # landmark removal in a bank of 512 filters of 150 landmarks, each dropping its own landmark
     Bb = 512
     gen.manual_seed(10)

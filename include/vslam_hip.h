@@ -107,6 +107,10 @@ vslam_status vslam_project(vslam_ctx *ctx, const vslam_camera *cam, const double
  * the blocks at 6-8, 9-11, 12+3j with the true pose angles. */
 vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
                                   int layout, double *h, double *SR, double *C, int32_t *code);
+/* The same evaluation with every array resident on the context's device (x, h, SR, C, code are device
+ * pointers; SR, C and code may be NULL).  Enqueued on the context's stream; returns without waiting. */
+vslam_status vslam_bundle_measure_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n,
+                                      int layout, double *h, double *SR, double *C, int32_t *code);
 /* MeasurementPointLandmarkSingle::operator(), src/measurementPointLandmark.hpp:10,33,46.
  * h[2], SR[4] or NULL, J (2 x n) or NULL; returns the projection code through *code. */
 vslam_status vslam_single_measure(vslam_ctx *ctx, const vslam_camera *cam, int j, const double *x, int n,

@@ -82,7 +82,7 @@ def test_one_frame_against_the_oracle(ctx, gcam, ocam, solver):
     try:
         ret_g, mup_g, Sp_g, it_g, ev_g = api.measurement_update_iekf(ctx, gcam, mu_g, S_g, y, visible, 7.0)
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
     ret_o, mup_o, Sp_o, it_o, ev_o = orc.measurement_update_iekf(mu_o, S_o, y, visible, ocam, 7.0)
     assert (ret_g, it_g, ev_g) == (ret_o, it_o, ev_o)
     scale = np.maximum(np.abs(mup_o), 1e-3)

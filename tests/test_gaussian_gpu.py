@@ -159,7 +159,7 @@ def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     try:
         ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
     assert ctx.last_trs_route() == (api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
     assert ret == 0 and ret0 == 0
@@ -189,7 +189,7 @@ def test_measurement_update_iekf_indefinite_falls_back(ctx, gcam, ocam):
     try:
         ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(mu, S, sc.y, sc.visible, ocam, sc.sigma)
     assert ctx.last_trs_route() == api.TRS_EIG
     assert (ret, iters, evals) == (ret0, iters0, evals0)
@@ -209,7 +209,7 @@ def test_measurement_update_iekf_2000_landmarks(ctx, gcam):
     try:
         ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, sc.S, sc.y, sc.visible, sc.sigma)
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
     assert ret == 0 and ctx.last_trs_route() == api.TRS_CHOLESKY
     assert not np.tril(Sp, -1).any()
     V0, g0, _ = api.cost_joint_density(ctx, gcam, mu, mu, sc.S, sc.y, sc.visible, sc.sigma)

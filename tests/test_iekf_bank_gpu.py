@@ -51,7 +51,87 @@ def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
             assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
             assert not np.tril(S1, -1).any()
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)
+
+
+@pytest.mark.parametrize("L,B,perturb", [(5, 4, False), (20, 3, False), (5, 4, True), (20, 3, True)])
+def test_bank_matches_the_cpu_restatement(ctx, gcam, ocam, L, B, perturb):
+    """The bank against the CPU restatement of measurementUpdateIEKF (eigenvalue trust-region route, as the
+    reference runs it), filter by filter: same return code, posterior mean to 1e-9 of its largest entry and
+    S^T S to 1e-9 relative where the iteration counts agree (they must for the five-landmark filters started at
+    the scene's own mean).  Elsewhere the last iterations are decided by rounding (|p.g| < 2 eps, rho of steps
+    the cost no longer resolves): the counts may differ and the results are compared against the posterior spread."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    scs, mus = _bank(L, B, 4100 + L, perturb)
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    y = torch.tensor(np.stack([sc.y for sc in scs]), device=dev)
+    vis = torch.tensor(np.stack([sc.visible for sc in scs]).astype(np.uint8), device=dev)
+    mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, scs[0].sigma, mup, Sp)
+    torch.cuda.synchronize()
+    assert not status.any()
+    same_count = 0
+    for b, sc in enumerate(scs):
+        ret, m0, S0, it0, _ = orc.measurement_update_iekf(mus[b], sc.S, sc.y, sc.visible, ocam, sc.sigma)
+        m1 = mup[b].cpu().numpy()
+        S1 = Sp[b].cpu().numpy().T
+        assert code[b] == ret
+        if not perturb and L == 5:
+            assert int(iters[b]) == it0
+        if int(iters[b]) == it0:
+            same_count += 1
+            assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+        else:
+            # Newton steps more or less at the point where |p.g| < 2 eps: the means differ by such a step, which
+            # is tiny against the posterior spread (|S^-T dm| = sqrt(p.H p) ~ sqrt(eps))
+            z = np.linalg.solve(S0.T, m1 - m0)
+            assert np.linalg.norm(z) <= 1e-6
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-6
+    assert same_count == B or perturb or L != 5
+
+
+def test_bank_with_collapsed_trust_region_matches_eigenvalue_route(ctx, gcam):
+    """Filters whose last iterations are rejected steps with a shrinking radius (the cost no longer resolves the
+    step, rho is rounding noise): there the bank's multiplier iteration stops on |ff| * Delta < 1e-10, before the
+    reference's |ff| < sqrt(eps).  The posterior must still agree with the eigenvalue route of the single-filter
+    entry to 1e-9; iteration counts may differ by the accept/reject decisions taken on rounding noise."""
+    import torch
+    from visualslam_amd import api
+    from visualslam_amd import synthetic as syn
+    L, B = 150, 3
+    scs = [syn.Scene(L, 9000 + i, dense_S=True) for i in range(B)]
+    rng = np.random.default_rng(1)
+    mus = np.stack([sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)])
+                    for sc in scs])
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    y = torch.tensor(np.stack([sc.y for sc in scs]), device=dev)
+    vis = torch.tensor(np.stack([sc.visible for sc in scs]).astype(np.uint8), device=dev)
+    mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, scs[0].sigma, mup, Sp)
+    torch.cuda.synchronize()
+    assert status[0] == 0 and iters[0] >= 7      # this filter goes through several rejected steps
+    ctx.set_trs_solver(api.TRS_EIG)
+    try:
+        for b, sc in enumerate(scs):
+            if status[b]:                         # an indefinite Hessian on the way: reported for the caller to redo
+                continue
+            c0, m0, S0, it0, _ = api.measurement_update_iekf(ctx, gcam, mus[b], sc.S, sc.y, sc.visible, sc.sigma)
+            assert ctx.last_trs_route() == api.TRS_EIG
+            m1 = mup[b].cpu().numpy()
+            S1 = Sp[b].cpu().numpy().T
+            assert code[b] == c0
+            assert abs(int(iters[b]) - it0) <= 4
+            assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+    finally:
+        ctx.set_trs_solver(api.TRS_CHOLESKY)
 
 
 def test_bank_rejects_bad_arguments(ctx, gcam):
@@ -121,4 +201,4 @@ def test_bank_larger_than_one_pass(ctx, gcam):
                 assert np.abs(m[b] - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
                 assert rel_err(P[b] @ P[b].T, S0.T @ S0) <= 1e-9
     finally:
-        ctx.set_trs_solver(api.TRS_EIG)
+        ctx.set_trs_solver(api.TRS_CHOLESKY)

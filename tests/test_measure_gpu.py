@@ -62,6 +62,43 @@ def test_bundle_vs_oracle(ctx, gcam, ocam, layout, L, seed):
     assert np.array_equal(C != 0, C0 != 0), "same sparsity pattern"
 
 
+@pytest.mark.parametrize("L,shift", [(3, 0), (150, 0), (150, 1), (2100, 0), (4500, 1)])
+def test_bundle_device_entry_fills_every_element(ctx, gcam, ocam, L, shift):
+    """vslam_bundle_measure_dev into NaN-filled device arrays (every element of the dense C and SR must be written,
+    zeros included), also at an 8-byte-aligned base address, against the host-pointer entry bit for bit; more than
+    2048 landmarks puts several landmarks into one workgroup."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    sc = syn.Scene(L, 77 + L, dense_S=False)
+    n, m = 12 + 3 * L, 2 * L
+    dev = torch.device("cuda:0")
+    x = torch.tensor(sc.x, device=dev)
+    h = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+    Cbuf = torch.full((m * n + 2,), float("nan"), dtype=torch.float64, device=dev)
+    Sbuf = torch.full((m * m + 2,), float("nan"), dtype=torch.float64, device=dev)
+    code = torch.full((L,), -1, dtype=torch.int32, device=dev)
+    Cd, Sd = Cbuf[shift:shift + m * n], Sbuf[shift:shift + m * m]
+    torch.cuda.synchronize()                    # the fills run on torch's stream, the library on the context's
+    api.bundle_measure_dev(ctx, gcam, x, h, Sd, Cd, code, layout=1)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    Cg = Cd.cpu().numpy().reshape(n, m).T
+    Sg = Sd.cpu().numpy().reshape(m, m).T
+    assert np.isnan(Cbuf[shift + m * n:].cpu().numpy()).all() and (shift == 0 or np.isnan(Cbuf[0].item()))
+    assert np.isnan(Sbuf[shift + m * m:].cpu().numpy()).all() and (shift == 0 or np.isnan(Sbuf[0].item()))
+    if L <= 2100:
+        h0, SR0, C0, code0 = api.bundle_measure(ctx, gcam, sc.x, 1)
+        assert np.array_equal(Cg, C0) and np.array_equal(Sg, SR0)
+        assert np.array_equal(h.cpu().numpy(), h0, equal_nan=True) and np.array_equal(code.cpu().numpy(), code0)
+    if L <= 150:
+        _, _, C1, _ = orc.bundle_measure(sc.x, ocam, 1)
+        assert rel_err(Cg, C1) <= TOL
+    assert not np.isnan(Cg).any() and np.array_equal(Sg, 0.01 * np.eye(m))
+    nz = np.count_nonzero(Cg, axis=0)
+    assert (nz[12:] <= 2).all()                 # a landmark column holds its own two rows only
+
+
 def test_bundle_golden(ctx, gcam):
     from visualslam_amd import api
     B = json.load(open(os.path.join(GOLDEN, "bundle.json")))

@@ -102,6 +102,7 @@ def _declare(L):
         "vslam_camera_from_xml": [C.c_char_p, C.POINTER(Camera)],
         "vslam_project": [_vp, C.POINTER(Camera), _vp, _i, _i, _i, _vp, _vp],
         "vslam_bundle_measure": [_vp, C.POINTER(Camera), _vp, _i, _i, _vp, _vp, _vp, _vp],
+        "vslam_bundle_measure_dev": [_vp, C.POINTER(Camera), _vp, _i, _i, _vp, _vp, _vp, _vp],
         "vslam_single_measure": [_vp, C.POINTER(Camera), _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
         "vslam_point_loglik": [_vp, C.POINTER(Camera), _vp, _i, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp],
         "vslam_point_loglik_batch_dev": [_vp, C.POINTER(Camera), _i, _i, _vp, _sz, _vp, _sz, _vp, _sz, _d,

@@ -136,6 +136,13 @@ def bundle_measure(ctx, cam, x, layout=LAYOUT_COMPAT, want_SR=True, want_C=True)
     return h, SR, Cm, code
 
 
+def bundle_measure_dev(ctx, cam, x, h, SR=None, Cm=None, code=None, layout=LAYOUT_COMPAT):
+    """Device-resident bundle evaluation: x (n), h (2L), SR (2L x 2L, column-major), Cm (2L x n, column-major) and
+    code (L, int32) are torch tensors on the context's device; SR, Cm and code may be None."""
+    n = x.numel()
+    check(ctx._L.vslam_bundle_measure_dev(ctx.ptr, C.byref(cam), _tp(x), n, layout, _tp(h), _tp(SR), _tp(Cm), _tp(code)), ctx.ptr)
+
+
 def single_measure(ctx, cam, j, x, layout=LAYOUT_COMPAT, want_SR=True, want_J=True):
     x = _f64(x)
     n = x.size

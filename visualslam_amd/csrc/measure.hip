@@ -9,9 +9,9 @@
 //   block 0   all L landmarks, one per lane: pixel, cull code and the six dense
 //             pose columns of C (rows 2j,2j+1 are 16 contiguous bytes per lane,
 //             contiguous across lanes); zero-fills the six all-zero columns.
-//   block p   P landmarks: streams zeros over their 3P columns of C and their
-//             2P columns of SR, then drops the 2x3 landmark block and the
-//             0.01 diagonal of SR in place.
+//   block p   P landmarks: one streaming pass over their 3P columns of C and their
+//             2P columns of SR, each 16-byte row pair written once (the 2x3 landmark
+//             block and the 0.01 diagonal of SR where they fall, zeros elsewhere).
 // C (2L x n) and SR (2L x 2L) are >97 % zeros but are dense outputs of the
 // reference interface, so the kernel is HBM-write bound.
 //
@@ -104,42 +104,64 @@ __global__ __launch_bounds__(kThreads) void bundle_measure_kernel(CamK cam, Bund
     if (is_cam) { jb = 0; je = L; }
     else { jb = (blockIdx.x - 1) * a.P; je = min(L, jb + a.P); }
 
-    if (is_cam) {
-        if (a.C) block_zero_cols_f64(a.C, m, m, strict ? 0 : n - 6, strict ? 6 : n);
-    } else {
-        if (a.C) block_zero_cols_f64(a.C, m, m, lm_c0 + 3 * jb, lm_c0 + 3 * je);
-        if (a.SR) block_zero_cols_f64(a.SR, m, m, 2 * jb, 2 * je);
+    if (!is_cam) {
+        // One pass over this panel's columns, every 16-byte pair of rows written exactly once: the pair
+        // (2j, 2j+1) of a column that belongs to landmark j carries the Jacobian entries (or 0.01 on the
+        // diagonal of SR), every other pair is zero.  Consecutive lanes write consecutive pairs, so a wave
+        // emits whole cache lines and no line is touched twice.
+        __shared__ double JPs[kThreads][6];
+        const int np = je - jb;
+        if (tid < np) {
+            const Pose pose = make_pose(a.x + 6);
+            const Pose prot = rot_pose(a.x, a.layout, pose);
+            Jac J;
+            landmark_jacobian(cam, pose, prot, a.x + 12 + 3 * (jb + tid), J);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { JPs[tid][2 * c] = J.JP[0][c]; JPs[tid][2 * c + 1] = J.JP[1][c]; }
+        }
         __syncthreads();
+        if (a.C) {
+            double *base = a.C + (size_t)(lm_c0 + 3 * jb) * m;
+            const int pairs = 3 * np * L;                          // m / 2 = L pairs per column
+            const bool aligned = (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+            for (int i = tid; i < pairs; i += kThreads) {
+                const int col = i / L, rr = i - col * L, jl = col / 3, c = col - 3 * jl;
+                double2 v = make_double2(0.0, 0.0);
+                if (rr == jb + jl) v = make_double2(JPs[jl][2 * c], JPs[jl][2 * c + 1]);
+                if (aligned) reinterpret_cast<double2 *>(base)[i] = v;
+                else { base[2 * (size_t)i] = v.x; base[2 * (size_t)i + 1] = v.y; }
+            }
+        }
+        if (a.SR) {
+            double *base = a.SR + (size_t)(2 * jb) * m;
+            const int pairs = 2 * np * L;
+            const bool aligned = (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+            for (int i = tid; i < pairs; i += kThreads) {
+                const int col = i / L, rr = i - col * L;
+                double2 v = make_double2(0.0, 0.0);
+                if (rr == jb + (col >> 1)) v = (col & 1) ? make_double2(0.0, 0.01) : make_double2(0.01, 0.0);
+                if (aligned) reinterpret_cast<double2 *>(base)[i] = v;
+                else { base[2 * (size_t)i] = v.x; base[2 * (size_t)i + 1] = v.y; }
+            }
+        }
+        return;
     }
+    if (a.C) block_zero_cols_f64(a.C, m, m, strict ? 0 : n - 6, strict ? 6 : n);
     if (jb + tid >= je) return;
     const Pose pose = make_pose(a.x + 6);
     const Pose prot = rot_pose(a.x, a.layout, pose);
     for (int j = jb + tid; j < je; j += kThreads) {
         Jac J;
         landmark_jacobian(cam, pose, prot, a.x + 12 + 3 * j, J);
-        if (is_cam) {
-            a.h[2 * j] = J.px[0]; a.h[2 * j + 1] = J.px[1];
-            if (a.code) a.code[j] = J.code;
-            if (a.C) {
+        a.h[2 * j] = J.px[0]; a.h[2 * j + 1] = J.px[1];
+        if (a.code) a.code[j] = J.code;
+        if (a.C) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double2 *colP = reinterpret_cast<double2 *>(a.C + (size_t)(cam_c0 + c) * m + 2 * j);
-                    double2 *colT = reinterpret_cast<double2 *>(a.C + (size_t)(cam_c0 + 3 + c) * m + 2 * j);
-                    *colP = make_double2(-J.JP[0][c], -J.JP[1][c]);
-                    *colT = make_double2(J.JT[0][c], J.JT[1][c]);
-                }
-            }
-        } else {
-            if (a.C) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double2 *col = reinterpret_cast<double2 *>(a.C + (size_t)(lm_c0 + 3 * j + c) * m + 2 * j);
-                    *col = make_double2(J.JP[0][c], J.JP[1][c]);
-                }
-            }
-            if (a.SR) {
-                a.SR[(size_t)(2 * j) * m + 2 * j] = 0.01;
-                a.SR[(size_t)(2 * j + 1) * m + 2 * j + 1] = 0.01;
+            for (int c = 0; c < 3; ++c) {
+                double2 *colP = reinterpret_cast<double2 *>(a.C + (size_t)(cam_c0 + c) * m + 2 * j);
+                double2 *colT = reinterpret_cast<double2 *>(a.C + (size_t)(cam_c0 + 3 + c) * m + 2 * j);
+                *colP = make_double2(-J.JP[0][c], -J.JP[1][c]);
+                *colT = make_double2(J.JT[0][c], J.JT[1][c]);
             }
         }
     }
@@ -252,6 +274,17 @@ extern "C" vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera 
     if (SR) VSLAM_TRY(d2h(ctx, SR, dSR, (size_t)m * m * 8));
     VSLAM_TRY(stream_sync(ctx));
     return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_bundle_measure_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *x, int n, int layout,
+                                                 double *h, double *SR, double *C, int32_t *code)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!x || !h) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure_dev: null pointer");
+    CamK k;
+    VSLAM_TRY(resolve_camera(ctx, cam, &k));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_bundle_measure(ctx, k, x, n, layout, h, SR, C, code);
 }
 
 extern "C" vslam_status vslam_single_measure(vslam_ctx *ctx, const vslam_camera *cam, int j, const double *x, int n,
