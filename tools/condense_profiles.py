@@ -25,6 +25,34 @@ def kernel_stats(db_path, csv_path):
     return {r[0]: {"calls": r[1], "avg_ns": r[3]} for r in rows}
 
 
+def trace_summary(db_path, txt_path, focus, reps):
+    """Per-kernel totals over the last of `reps` equal repetitions in a kernel trace, the durations of the
+    `focus` kernel and the idle gaps between its consecutive launches."""
+    db = sqlite3.connect(db_path)
+    rows = [r for r in db.execute("select name, start, end from kernels order by start") if "vslam" in r[0]]
+    n = len(rows) // reps
+    last = rows[-n:]
+    t0, t1 = last[0][1], max(r[2] for r in last)
+    tot = {}
+    for name, a, b in last:
+        k = name.split("(")[0][-70:]
+        c = tot.setdefault(k, [0, 0.0])
+        c[0] += 1
+        c[1] += (b - a) / 1e3
+    busy = sum(v[1] for v in tot.values())
+    with open(txt_path, "w") as f:
+        f.write("last of %d repetitions: span %.3f ms over %d dispatches, kernels busy %.3f ms\n" % (reps, (t1 - t0) / 1e6, n, busy / 1e3))
+        for k, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-72s %5d calls %10.1f us  avg %8.1f  %5.1f %% of span\n" % (k, c, us, us / c, 100.0 * us / ((t1 - t0) / 1e3)))
+        sel = [r for r in last if focus in r[0]]
+        if sel:
+            d = [(b - a) / 1e3 for _, a, b in sel]
+            gaps = [(y[1] - x[2]) / 1e3 for x, y in zip(sel, sel[1:])]
+            f.write("%s: %d launches, durations us %s\n" % (focus, len(sel), [round(x) for x in d]))
+            f.write("gaps between consecutive launches us %s\n" % [round(x) for x in gaps])
+            f.write("sum of durations %.1f us (%.1f %% of span), sum of gaps %.1f us\n" % (sum(d), 100.0 * sum(d) / ((t1 - t0) / 1e3), sum(gaps)))
+
+
 def counters(db_path, names):
     db = sqlite3.connect(db_path)
     out = {}
@@ -41,6 +69,11 @@ def main():
     os.makedirs(DST, exist_ok=True)
     stats = kernel_stats(os.path.join(SRC, "bench", "bench_results.db"), os.path.join(DST, tag + "_bench_kernel_stats.csv"))
     kernel_stats(os.path.join(SRC, "qr", "qr_results.db"), os.path.join(DST, tag + "_qr6012_kernel_stats.csv"))
+    trace_summary(os.path.join(SRC, "qr", "qr_results.db"), os.path.join(DST, tag + "_qr6012_trace_summary.txt"), "qr_block_kernel", 3)
+    for name, focus in (("bank_affine", "qr_block_kernel"), ("bank_iekf", "potf2_upper_kernel"), ("c4", "qr_block_kernel")):
+        dbp = os.path.join(SRC, name, name + "_results.db")
+        if os.path.exists(dbp):
+            kernel_stats(dbp, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
     with open(os.path.join(SRC, "bench.log")) as f:
         line = [l for l in f if l.startswith("{")][-1]
     with open(os.path.join(DST, tag + "_bench.json"), "w") as f:
@@ -91,7 +124,7 @@ def main():
                    "workload": "64 frames 1920x1080, both detectors", "mean_per_launch": sq}, f, indent=1)
     mf_db = os.path.join(SRC, "qr_mfma", "mfma_results.db")
     if os.path.exists(mf_db) and not os.path.exists(os.path.join(SRC, "qr_mfma.failed")):
-        mf = counters(mf_db, ["gemm_f64_kernel", "qr_panel_coop_kernel"])
+        mf = counters(mf_db, ["gemm_f64_kernel", "qr_block_kernel", "qr_panel_coop_kernel"])
         with open(os.path.join(DST, tag + "_qr6012_mfma_counters.json"), "w") as f:
             json.dump({"command": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA "
                                   "-- python3 tools/qr_bench.py 6012 6012 1",

@@ -15,4 +15,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/corner_fetch" -o fetch -
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/corner_write" -o write -- python3 "$R/tools/run_corner.py" 64 3 > "$OUT/corner_write.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/qr" -o qr -- python3 "$R/tools/qr_bench.py" 6012 6012 2 > "$OUT/qr.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA -d "$OUT/qr_mfma" -o mfma -- python3 "$R/tools/qr_bench.py" 6012 6012 1 > "$OUT/qr_mfma.log" 2>&1 || echo "mfma counter pass failed (counter names may differ)" > "$OUT/qr_mfma.failed"
-ls -R "$OUT" | head -40
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_affine" -o bank_affine -- python3 "$R/tools/run_bank_affine.py" 512 150 3 > "$OUT/bank_affine.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_iekf" -o bank_iekf -- python3 "$R/tools/run_iekf_bank.py" 150 512 --batched > "$OUT/bank_iekf.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/c4" -o c4 -- python3 "$R/tools/run_c4.py" > "$OUT/c4.log" 2>&1 || echo "config-4 trace failed" > "$OUT/c4.failed"
+ls -R "$OUT" | head -60
