@@ -414,8 +414,7 @@ vslam_status vslam_fast9_detect_batch_dev(vslam_ctx *ctx, const uint8_t *gray, i
                                           vslam_feature *out, int cap, int32_t *count);
 
 /* ---- ORB keypoints: cv::ORB::create(nfeatures, 1.2f, 8, 75, 0, 2, HARRIS_SCORE, 75, 20)->detect as called by
- * detectAndDrawORB, src/imagefeatures.cpp:73-87 (keypoints only: orientation and the rBRIEF descriptors need OpenCV's
- * learned sampling pattern, which is neither in the reference nor reproducible here).  OpenCV's sources are not
+ * detectAndDrawORB, src/imagefeatures.cpp:73-87 (orientation and descriptors follow further down).  OpenCV's sources are not
  * part of the reference: the chain below restates the published algorithm and the CPU oracle defines the contract
  * ("parity unpinned").  Per pyramid level: FAST-9/16 at fast_threshold with non-maximum suppression; corners closer
  * than edge_threshold to a side dropped; the 2 n strongest by FAST score kept, every tie of the last one included;
@@ -453,6 +452,35 @@ vslam_status vslam_resize_bilinear_dev(vslam_ctx *ctx, const uint8_t *src, int s
  * level_counts (optional) receives the number per level. */
 vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *params,
                               vslam_orb_keypoint *out, int cap, int32_t *count, int32_t *level_counts);
+
+/* ---- ORB orientation and descriptors: the compute() half of detectAndDrawORB's cv::ORB
+ * (src/imagefeatures.cpp:88-96), whose 32-byte descriptors BFMatcher(NORM_HAMMING) consumes (src/SLAM.cpp:222,355;
+ * vslam_match_hamming here).  Restated from the published algorithm, the CPU oracle defines the contract
+ * ("parity unpinned"):
+ *   orientation  intensity centroid of the radius-15 circular patch on the keypoint's level image, degrees in
+ *                [0, 360) by the polynomial arctangent of cv::fastAtan2;
+ *   blur         7 x 7 Gaussian, sigma 2, reflect-101 borders, 8.8 fixed point with weights
+ *                {18, 34, 49, 54, 49, 34, 18} / 256 (this library's definition, not OpenCV's fixed-point kernel);
+ *   descriptor   256 tests I(p0) < I(p1) on the blurred level image, pattern points rotated by the angle and rounded
+ *                half to even; bit k of byte i is test 8 i + k.
+ * The pattern is 256 x (x0, y0, x1, y1) signed bytes, every coordinate in [-15, 15].  cv::ORB's learned table lives
+ * only in OpenCV's sources: a caller who needs cv::ORB's bits passes that table; NULL selects the fixed
+ * pseudo-random table returned by vslam_orb_default_pattern (descriptors then match each other, not OpenCV's). */
+#define VSLAM_ORB_PATTERN_BYTES 1024
+vslam_status vslam_orb_default_pattern(int8_t *pattern);
+/* The blur on its own (device pointers). */
+vslam_status vslam_gaussian_blur7_dev(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+/* Orientation and descriptors of the keypoints of one level (all pointers on the device): keypoints[0 ..
+ * min(*count, max_count)) in level coordinates, gray = the level image, blurred = its blur, pattern 16-byte
+ * aligned; angle[max_count], desc[max_count][32].  A keypoint closer than 23 pixels to a side gets angle -1 and a
+ * zero descriptor. */
+vslam_status vslam_orb_describe_level_dev(vslam_ctx *ctx, const uint8_t *gray, int stride, const uint8_t *blurred, int bstride,
+                                          int w, int h, const vslam_feature *keypoints, const int32_t *count, int max_count,
+                                          const int8_t *pattern, float *angle, uint8_t *desc);
+/* vslam_orb_detect plus angle[cap] and desc[cap][32] for every keypoint (pattern: host table or NULL). */
+vslam_status vslam_orb_detect_and_compute(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *params,
+                                          const int8_t *pattern, vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap,
+                                          int32_t *count, int32_t *level_counts);
 
 #ifdef __cplusplus
 }

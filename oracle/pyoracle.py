@@ -432,6 +432,68 @@ def orb_detect(gray, nfeatures=10000, scale_factor=1.2, nlevels=8, edge=75, fast
     return out, ls
 
 
+_lib.orc_fast_atan2.restype = C.c_float
+_lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+_lib.orc_orb_ic_angle.restype = C.c_float
+
+
+def gaussian_blur7(gray):
+    """7 x 7 Gaussian, sigma 2, reflect-101 borders, in the fixed point this library defines (see vslam_oracle.c)."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    dst = np.zeros((h, w), dtype=np.uint8)
+    _lib.orc_gaussian_blur7(_b(gray), w, h, w, _b(dst), w)
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(_lib.orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def orb_default_pattern():
+    pat = np.zeros(1024, dtype=np.int8)
+    _lib.orc_orb_default_pattern(pat.ctypes.data_as(C.c_void_p))
+    return pat
+
+
+def orb_describe_level(gray, kps, pattern=None, blur=None):
+    """Orientation (degrees) and 32-byte descriptors of keypoints `kps` (FEATURE_DTYPE, level coordinates) on one
+    level image: cv::ORB::compute as the reference calls it (src/imagefeatures.cpp:88-96), restated; parity unpinned."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    blur = gaussian_blur7(gray) if blur is None else np.ascontiguousarray(blur, dtype=np.uint8)
+    pattern = orb_default_pattern() if pattern is None else np.ascontiguousarray(pattern, dtype=np.int8)
+    n = len(kps)
+    angle = np.zeros(n, dtype=np.float32)
+    desc = np.zeros((n, 32), dtype=np.uint8)
+    for i in range(n):
+        x, y = int(kps["x"][i]), int(kps["y"][i])
+        angle[i] = _lib.orc_orb_ic_angle(_b(gray), w, x, y, None, None)
+        _lib.orc_orb_describe(_b(blur), w, x, y, C.c_float(angle[i]), pattern.ctypes.data_as(C.c_void_p),
+                              desc[i].ctypes.data_as(C.c_void_p))
+    return angle, desc
+
+
+def orb_detect_and_compute(gray, nfeatures=10000, scale_factor=1.2, nlevels=8, edge=75, fast_threshold=20, block=7, harris_k=0.04,
+                           pattern=None):
+    """orb_detect plus orientation and descriptors: lists over levels of keypoints, angles, descriptors; scales."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    lw, lh, lf, ls = orb_level_plan(w, h, nfeatures, scale_factor, nlevels)
+    kps, angles, descs, img = [], [], [], gray
+    for l in range(nlevels):
+        if l > 0:
+            img = resize_bilinear(img, int(lw[l]), int(lh[l]))
+        if lw[l] < 2 * edge + 1 or lh[l] < 2 * edge + 1:
+            kps.append(np.zeros(0, dtype=FEATURE_DTYPE)); angles.append(np.zeros(0, dtype=np.float32))
+            descs.append(np.zeros((0, 32), dtype=np.uint8))
+            continue
+        k = orb_detect_level(img, int(lf[l]), fast_threshold, edge, block, harris_k)
+        a, d = orb_describe_level(img, k, pattern)
+        kps.append(k); angles.append(a); descs.append(d)
+    return kps, angles, descs, ls
+
+
 def normcdf(z):
     return float(_lib.orc_normcdf(float(z)))
 

@@ -1660,3 +1660,122 @@ void orc_initialize_landmark(const double *mu, const double *S, int n, int ldS, 
     for (int i = 0; i < 3; ++i)
         mu_out[n + i] = mu[6 + i] + (R[i + 3 * 0] * ray[0] + R[i + 3 * 1] * ray[1] + R[i + 3 * 2] * ray[2]);
 }
+
+/* ------------------------------------------------------------------ */
+/* ORB orientation and rBRIEF descriptors: the compute() half of cv::ORB as detectAndDrawORB calls it
+ * (reference src/imagefeatures.cpp:88-96; the descriptors feed BFMatcher(NORM_HAMMING), src/SLAM.cpp:222,355).
+ * OpenCV is a dependency that is not part of the reference tree, so what follows restates the published ORB
+ * algorithm (Rublee et al. 2011) with OpenCV's conventions as documented; parity unpinned.
+ *   orientation: intensity centroid of the circular patch of radius 15 around the keypoint on the level image,
+ *                angle = atan2(m01, m10) in degrees by the 7th-order odd polynomial of cv::fastAtan2;
+ *   blur:        7 x 7 Gaussian, sigma 2, reflect-101 borders, on the level image.  Fixed point: the weights are
+ *                round(256 g_i) with the centre weight taking the remainder {18, 34, 49, 54, 49, 34, 18}, the row
+ *                pass is exact, the column pass rounds (sum + 2^15) >> 16.  This library's own definition (OpenCV's
+ *                8-bit GaussianBlur uses its own fixed-point kernel and is not reproduced).
+ *   descriptor:  256 binary tests I(p0) < I(p1) on the blurred level image, the test points rotated by the angle:
+ *                x' = round(x a - y b), y' = round(x b + y a), a = (float)cos, b = (float)sin of the angle in
+ *                radians (float), products and sums in float, rounding half to even; bit k of byte i = test 8 i + k.
+ *   pattern:     256 x (x0, y0, x1, y1), |coordinate| <= 13.  cv::ORB uses a learned table that exists only in
+ *                OpenCV's sources; a caller who wants cv::ORB's bits passes that table.  The default below is a fixed
+ *                pseudo-random table of this library. */
+static const int orc_gauss7_w[7] = {18, 34, 49, 54, 49, 34, 18};
+static int orc_reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i; return i; }
+
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            unsigned acc = 0;
+            for (int j = -3; j <= 3; ++j) {
+                const uint8_t *row = src + (size_t)orc_reflect101(y + j, h) * sstride;
+                unsigned hsum = 0;
+                for (int i = -3; i <= 3; ++i) hsum += (unsigned)orc_gauss7_w[i + 3] * row[orc_reflect101(x + i, w)];
+                acc += (unsigned)orc_gauss7_w[j + 3] * hsum;
+            }
+            dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+        }
+}
+
+/* half-widths of the rows of the circular patch of radius 15: u_max[v], v = 0..15 */
+void orc_orb_umax(int *umax)
+{
+    const int hp = 15;
+    int v, v0, vmax = (int)floor(hp * sqrt(2.0) / 2 + 1), vmin = (int)ceil(hp * sqrt(2.0) / 2);
+    for (v = 0; v <= hp + 1; ++v) umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)nearbyint(sqrt((double)hp * hp - (double)v * v));
+    for (v = hp, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+/* angle in degrees in [0, 360): the polynomial approximation of cv::fastAtan2 (maximum error about 0.3 degrees) */
+float orc_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+float orc_orb_ic_angle(const uint8_t *gray, int stride, int x, int y, int *m01_out, int *m10_out)
+{
+    int umax[17];
+    orc_orb_umax(umax);
+    int m01 = 0, m10 = 0;
+    for (int v = -15; v <= 15; ++v) {
+        const int d = umax[v < 0 ? -v : v];
+        const uint8_t *row = gray + (size_t)(y + v) * stride + x;
+        for (int u = -d; u <= d; ++u) { m10 += u * row[u]; m01 += v * row[u]; }
+    }
+    if (m01_out) *m01_out = m01;
+    if (m10_out) *m10_out = m10;
+    return orc_fast_atan2((float)m01, (float)m10);
+}
+
+void orc_orb_default_pattern(int8_t *pattern)
+{
+    uint32_t st = 0x34985739u;
+    for (int i = 0; i < 256; ++i) {
+        int c[4];
+        do {
+            for (int k = 0; k < 4; ++k) { st = st * 1664525u + 1013904223u; c[k] = (int)((st >> 16) % 27u) - 13; }
+        } while (c[0] == c[2] && c[1] == c[3]);
+        for (int k = 0; k < 4; ++k) pattern[4 * i + k] = (int8_t)c[k];
+    }
+}
+
+void orc_orb_describe(const uint8_t *blur, int stride, int x, int y, float angle_deg, const int8_t *pattern, uint8_t *desc)
+{
+    const float angle = angle_deg * (float)(3.14159265358979323846 / 180.0);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const uint8_t *center = blur + (size_t)y * stride + x;
+    for (int i = 0; i < 32; ++i) {
+        int val = 0;
+        for (int k = 0; k < 8; ++k) {
+            const int8_t *t = pattern + 4 * (8 * i + k);
+            int v[2];
+            for (int q = 0; q < 2; ++q) {
+                const float px = (float)t[2 * q], py = (float)t[2 * q + 1];
+                const float fx = px * a - py * b, fy = px * b + py * a;
+                const int ix = (int)nearbyintf(fx), iy = (int)nearbyintf(fy);
+                v[q] = center[(long)iy * stride + ix];
+            }
+            val |= (v[0] < v[1]) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}

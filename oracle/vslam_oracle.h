@@ -202,6 +202,13 @@ int orc_orb_detect_level(const uint8_t *gray, int w, int h, int stride, int nfea
                          int block, float harris_k, orc_feature *out, int cap);
 void orc_resize_bilinear(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride);
 void orc_orb_level_plan(int nfeatures, float scale_factor, int nlevels, int w, int h, int *lw, int *lh, int *lf, float *ls);
+/* orientation and rBRIEF descriptors of cv::ORB::compute (reference src/imagefeatures.cpp:88-96), restated; parity unpinned */
+void orc_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride);
+void orc_orb_umax(int *umax);
+float orc_fast_atan2(float y, float x);
+float orc_orb_ic_angle(const uint8_t *gray, int stride, int x, int y, int *m01_out, int *m10_out);
+void orc_orb_default_pattern(int8_t *pattern);
+void orc_orb_describe(const uint8_t *blur, int stride, int x, int y, float angle_deg, const int8_t *pattern, uint8_t *desc);
 
 #ifdef __cplusplus
 }

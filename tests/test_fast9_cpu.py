@@ -75,3 +75,75 @@ def test_orb_level_plan_matches_published_series():
     assert lf.sum() == 10000 and lf[0] == 2172
     glw, glh, glf, gls = api.orb_level_plan(api.orb_params(), 1920, 1080)
     assert np.array_equal(glw, lw) and np.array_equal(glh, lh) and np.array_equal(glf, lf) and np.array_equal(gls, ls)
+
+
+def test_orientation_follows_a_rotated_patch():
+    """A bright half-plane through the keypoint: the intensity centroid points into the bright side, so the angle
+    follows the direction the half-plane is turned to (to the accuracy of the discretised patch)."""
+    from oracle import pyoracle as orc
+    size = 96
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64) - size // 2
+    for deg in (0, 45, 90, 200, 315):
+        t = np.deg2rad(deg)
+        img = np.where(xx * np.cos(t) + yy * np.sin(t) > 0, 220, 30).astype(np.uint8)
+        kp = np.zeros(1, dtype=orc.FEATURE_DTYPE)
+        kp["x"], kp["y"] = size // 2, size // 2
+        ang, _ = orc.orb_describe_level(img, kp)
+        d = abs(float(ang[0]) - deg)
+        assert min(d, 360 - d) < 3.0
+
+
+def test_polynomial_arctangent_stays_close_to_atan2():
+    """cv::fastAtan2's polynomial: degrees in [0, 360), within 0.02 degrees of atan2 (OpenCV documents 0.3)."""
+    import math
+    from oracle import pyoracle as orc
+    worst = 0.0
+    for t in np.linspace(-math.pi, math.pi, 1441):
+        y, x = 1000 * math.sin(t), 1000 * math.cos(t)
+        a = orc.fast_atan2(y, x)
+        assert 0.0 <= a <= 360.0
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - ref)
+        worst = max(worst, min(d, 360.0 - d))
+    assert worst < 0.02
+    assert orc.fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_blur_is_a_unit_gain_gaussian():
+    import scipy.ndimage as ndi
+    from oracle import pyoracle as orc
+    img = np.random.default_rng(12).integers(0, 256, (90, 140), dtype=np.uint8)
+    got = orc.gaussian_blur7(img).astype(np.float64)
+    want = ndi.gaussian_filter(img.astype(np.float64), 2.0, mode="mirror", truncate=1.5)     # 7 taps, reflect-101
+    assert np.abs(got - want).max() <= 2.0 and abs((got - want).mean()) < 0.2
+    flat = np.full((20, 30), 77, dtype=np.uint8)
+    assert (orc.gaussian_blur7(flat) == 77).all()
+
+
+def test_default_pattern_is_fixed_and_inside_the_patch():
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    pat = orc.orb_default_pattern()
+    assert pat.shape == (1024,) and pat.min() >= -13 and pat.max() <= 13
+    assert np.array_equal(pat, api.orb_default_pattern())                                   # library and oracle hold the same table
+    t = pat.reshape(256, 4)
+    assert not ((t[:, 0] == t[:, 2]) & (t[:, 1] == t[:, 3])).any()                         # no test compares a point with itself
+    assert list(pat[:8]) == [2, -10, -9, 11, 13, -12, 12, -1]
+
+
+def test_descriptor_of_a_rotated_image_is_stable():
+    """rBRIEF steers the pattern by the patch orientation: a keypoint described on an image and on the same image
+    turned by 90 degrees gets nearly the same bits (exactly, up to the arctangent's and the rounding's noise)."""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(21)
+    import scipy.ndimage as ndi
+    img = np.clip(ndi.gaussian_filter(rng.normal(128, 60, (161, 161)), 3.0) * 4 - 384, 0, 255).astype(np.uint8)
+    kp = np.zeros(1, dtype=orc.FEATURE_DTYPE)
+    kp["x"], kp["y"] = 80, 80
+    a0, d0 = orc.orb_describe_level(img, kp)
+    a1, d1 = orc.orb_describe_level(np.ascontiguousarray(np.rot90(img)), kp)               # centre pixel stays in place
+    turn = (float(a0[0]) - float(a1[0])) % 360.0
+    assert min(abs(turn - 90.0), abs(turn - 270.0)) < 1.0
+    differing = int(np.unpackbits(d0[0] ^ d1[0]).sum())
+    assert differing <= 40                                                                  # 256 bits; unrelated patches differ in ~128
+

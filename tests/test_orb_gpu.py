@@ -133,3 +133,133 @@ def test_orb_errors(ctx):
         api.orb_detect(ctx, img, api.orb_params(nlevels=40))
     kps, lev = api.orb_detect(ctx, img, api.orb_params(nfeatures=500))      # levels that fit inside the edge: none has corners
     assert kps.size == 0 and not lev.any()
+
+
+# ---- orientation and descriptors (cv::ORB::compute as the reference calls it, src/imagefeatures.cpp:88-96) ----
+@pytest.mark.parametrize("shape", [(1080, 1920), (301, 517), (64, 64), (1, 9), (7, 1)])
+def test_gaussian_blur_identical_to_oracle(ctx, shape):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    img = np.random.default_rng(shape[0]).integers(0, 256, shape, dtype=np.uint8)
+    src = torch.tensor(img, device="cuda:0")
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    api.gaussian_blur7_dev(ctx, src, dst)
+    ctx.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), orc.gaussian_blur7(img))
+
+
+def test_blur_of_a_constant_image_is_the_constant(ctx):
+    import torch
+    from visualslam_amd import api
+    src = torch.full((100, 130), 201, dtype=torch.uint8, device="cuda:0")
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    api.gaussian_blur7_dev(ctx, src, dst)
+    ctx.synchronize()
+    assert (dst == 201).all()
+
+
+@pytest.mark.parametrize("name", ["synthetic1080p", "noise", "own_pattern"])
+def test_level_orientation_and_descriptors_identical_to_oracle(ctx, name):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    if name == "noise":
+        img = np.random.default_rng(4).integers(0, 256, (600, 800), dtype=np.uint8)
+    else:
+        img = syn.frame(6)
+    pattern = orc.orb_default_pattern()
+    if name == "own_pattern":                                  # a caller's table with the largest coordinates allowed
+        pattern = np.random.default_rng(9).integers(-15, 16, 1024).astype(np.int8)
+    kps = orc.orb_detect_level(img, 1500)
+    assert kps.size > 200
+    want_angle, want_desc = orc.orb_describe_level(img, kps, pattern)
+    dev = torch.device("cuda:0")
+    g = torch.tensor(img, device=dev)
+    b = torch.zeros_like(g)
+    kp_t = torch.tensor(kps.view(np.int32).reshape(-1, 3), device=dev)
+    cnt = torch.tensor([kps.size], dtype=torch.int32, device=dev)
+    pat = torch.tensor(pattern, device=dev)
+    cap = kps.size + 7
+    angle = torch.full((cap,), -5.0, dtype=torch.float32, device=dev)
+    desc = torch.full((cap, 32), 0xAA, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    api.gaussian_blur7_dev(ctx, g, b)
+    api.orb_describe_level_dev(ctx, g, b, kp_t, cnt, cap, pat, angle, desc)
+    ctx.synchronize()
+    got_angle, got_desc = angle.cpu().numpy(), desc.cpu().numpy()
+    assert np.array_equal(got_angle[:kps.size].view(np.uint32), want_angle.view(np.uint32))      # bit for bit
+    assert np.array_equal(got_desc[:kps.size], want_desc)
+    assert (got_angle[kps.size:] == -5.0).all() and (got_desc[kps.size:] == 0xAA).all()           # nothing past the count
+    assert (want_angle >= 0).all() and (want_angle <= 360).all()
+    assert 0.35 < np.unpackbits(want_desc).mean() < 0.65                                          # tests are not degenerate
+
+
+def test_keypoint_too_close_to_the_side_gets_no_descriptor(ctx):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    img = np.random.default_rng(5).integers(0, 256, (120, 160), dtype=np.uint8)
+    kps = np.zeros(3, dtype=orc.FEATURE_DTYPE)
+    kps["x"], kps["y"] = [22, 80, 137], [60, 60, 60]          # 22 and 137 = 160 - 23 are one pixel too close
+    kps["x"][2] = 137
+    dev = torch.device("cuda:0")
+    g = torch.tensor(img, device=dev)
+    b = torch.zeros_like(g)
+    angle = torch.zeros(3, dtype=torch.float32, device=dev)
+    desc = torch.full((3, 32), 7, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    api.gaussian_blur7_dev(ctx, g, b)
+    api.orb_describe_level_dev(ctx, g, b, torch.tensor(kps.view(np.int32).reshape(-1, 3), device=dev),
+                               torch.tensor([3], dtype=torch.int32, device=dev), 3, torch.tensor(orc.orb_default_pattern(), device=dev), angle, desc)
+    ctx.synchronize()
+    a, d = angle.cpu().numpy(), desc.cpu().numpy()
+    assert a[0] == -1.0 and a[2] == -1.0 and not d[0].any() and not d[2].any()
+    wa, wd = orc.orb_describe_level(img, kps[1:2])
+    assert a[1] == wa[0] and np.array_equal(d[1], wd[0])
+
+
+def test_detect_and_compute_all_levels_and_matching(ctx):
+    """The whole front end on one frame against the oracle, level by level, then the use the reference makes of the
+    descriptors: Hamming nearest neighbours between a frame and a shifted copy of it (src/SLAM.cpp:222,355)."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    img = syn.frame(11)
+    params = api.orb_params(nfeatures=2000)
+    kp, angle, desc, lev = api.orb_detect_and_compute(ctx, img, params)
+    okp, oang, odesc, scales = orc.orb_detect_and_compute(img, nfeatures=2000)
+    assert [int(v) for v in lev] == [k.size for k in okp] and kp.size == sum(k.size for k in okp) > 500
+    pos = 0
+    for l, (k, a, d) in enumerate(zip(okp, oang, odesc)):
+        sl = slice(pos, pos + k.size)
+        assert (kp["octave"][sl] == l).all()
+        assert np.array_equal(angle[sl].view(np.uint32), a.view(np.uint32)) and np.array_equal(desc[sl], d)
+        pos += k.size
+    same = api.orb_detect(ctx, img, params)[0]
+    assert np.array_equal(same, kp)                             # the description stage leaves the detection alone
+    # level-0 keypoints of the frame moved 5 pixels to the right find themselves again
+    shifted = np.roll(img, 5, axis=1)
+    kp2, ang2, desc2, lev2 = api.orb_detect_and_compute(ctx, shifted, params)
+    n0, m0 = int(lev[0]), int(lev2[0])
+    dev = torch.device("cuda:0")
+    q = torch.tensor(desc[:n0][None], device=dev)
+    t = torch.tensor(desc2[:m0][None], device=dev)
+    idx = torch.zeros((1, n0), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    api.match_hamming_batch_dev(ctx, q, t, idx)
+    ctx.synchronize()
+    j = idx[0].cpu().numpy()
+    dx = kp2["x"][:m0][j] - kp["x"][:n0]
+    dy = kp2["y"][:m0][j] - kp["y"][:n0]
+    assert np.mean((dx == 5) & (dy == 0)) > 0.8
+
+
+def test_detect_and_compute_rejects_a_bad_pattern(ctx):
+    from visualslam_amd import api, synthetic as syn
+    pat = api.orb_default_pattern()
+    pat[17] = 16
+    with pytest.raises(api.VslamError):
+        api.orb_detect_and_compute(ctx, syn.frame(1), api.orb_params(nfeatures=100), pattern=pat)

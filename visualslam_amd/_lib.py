@@ -146,6 +146,10 @@ def _declare(L):
         "vslam_orb_detect_level_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _i, _i, C.c_float, _vp, _i, _vp],
         "vslam_resize_bilinear_dev": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i],
         "vslam_orb_detect": [_vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _vp, _i, _vp, _vp],
+        "vslam_orb_default_pattern": [_vp],
+        "vslam_gaussian_blur7_dev": [_vp, _vp, _i, _i, _i, _vp, _i],
+        "vslam_orb_describe_level_dev": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+        "vslam_orb_detect_and_compute": [_vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _vp, _vp, _vp, _vp, _i, _vp, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
     }
     for name, args in sig.items():

@@ -470,6 +470,43 @@ def orb_detect(ctx, gray, params=None, cap=32768):
     return out[:int(cnt[0])].copy(), lev
 
 
+def orb_default_pattern():
+    """The library's own 256 x (x0, y0, x1, y1) test pattern (int8[1024]); cv::ORB's learned table is a caller's input."""
+    pat = np.zeros(1024, dtype=np.int8)
+    check(_lib.lib().vslam_orb_default_pattern(_p(pat)))
+    return pat
+
+
+def orb_detect_and_compute(ctx, gray, params=None, pattern=None, cap=32768):
+    """ORB keypoints of all pyramid levels with orientation (degrees) and 32-byte descriptors:
+    (keypoints, angles, descriptors, per-level counts)."""
+    params = orb_params() if params is None else params
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    h, w = gray.shape
+    out = np.zeros(cap, dtype=ORB_KEYPOINT_DTYPE)
+    angle = np.zeros(cap, dtype=np.float32)
+    desc = np.zeros((cap, 32), dtype=np.uint8)
+    cnt = np.zeros(1, dtype=np.int32)
+    lev = np.zeros(params.nlevels, dtype=np.int32)
+    pat = None if pattern is None else np.ascontiguousarray(pattern, dtype=np.int8)
+    check(ctx._L.vslam_orb_detect_and_compute(ctx.ptr, _p(gray), w, h, w, C.byref(params), _p(pat), _p(out), _p(angle), _p(desc), cap,
+                                              _p(cnt), _p(lev)), ctx.ptr)
+    k = int(cnt[0])
+    return out[:k].copy(), angle[:k].copy(), desc[:k].copy(), lev
+
+
+def gaussian_blur7_dev(ctx, src, dst):
+    """src and dst (h, w) uint8 torch tensors on the GPU, rows contiguous."""
+    check(ctx._L.vslam_gaussian_blur7_dev(ctx.ptr, _tp(src), src.shape[1], src.shape[0], src.stride(0), _tp(dst), dst.stride(0)), ctx.ptr)
+
+
+def orb_describe_level_dev(ctx, gray, blurred, keypoints, count, max_count, pattern, angle, desc):
+    """Orientation and descriptors of one level's keypoints; every argument a torch tensor on the GPU (gray, blurred
+    (h, w) uint8; keypoints a FEATURE record buffer; count int32[1]; pattern int8[1024]; angle float32; desc uint8 (., 32))."""
+    check(ctx._L.vslam_orb_describe_level_dev(ctx.ptr, _tp(gray), gray.stride(0), _tp(blurred), blurred.stride(0), gray.shape[1], gray.shape[0],
+                                              _tp(keypoints), _tp(count), int(max_count), _tp(pattern), _tp(angle), _tp(desc)), ctx.ptr)
+
+
 def orb_detect_level_batch_dev(ctx, gray, w, h, stride, stride_frame, frames, nfeatures, out, cap, count,
                                fast_threshold=20, edge_threshold=75, harris_block=7, harris_k=0.04):
     check(ctx._L.vslam_orb_detect_level_batch_dev(ctx.ptr, _tp(gray), w, h, stride, stride_frame, frames, int(nfeatures), int(fast_threshold),

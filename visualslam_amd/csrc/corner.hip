@@ -28,6 +28,7 @@
 // keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
 // unpacks the leading keys into Feature records.
 #include "common.hpp"
+#include "orb.hpp"
 
 #include <cmath>
 #include <vector>
@@ -1194,15 +1195,22 @@ extern "C" vslam_status vslam_orb_level_plan(const vslam_orb_params *p, int w, i
     return VSLAM_OK;
 }
 
-extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *p,
-                                         vslam_orb_keypoint *out, int cap, int32_t *count, int32_t *level_counts)
+// All levels of one host image.  With desc != nullptr the keypoints of every level are also oriented and described
+// on that level (pattern: host table or nullptr for the library's own).
+static vslam_status orb_run(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *p, const int8_t *pattern,
+                            vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap, int32_t *count, int32_t *level_counts)
 {
-    if (!ctx) return VSLAM_ERR_ARG;
-    if (!gray || !p || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: null pointer or cap < 1");
+    const bool describe = desc != nullptr;
     int32_t lw[VSLAM_ORB_MAX_LEVELS], lh[VSLAM_ORB_MAX_LEVELS], lf[VSLAM_ORB_MAX_LEVELS];
     float ls[VSLAM_ORB_MAX_LEVELS];
     if (vslam_orb_level_plan(p, w, h, lw, lh, lf, ls) != VSLAM_OK) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: bad pyramid parameters");
     if (stride < w) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect: stride %d < width %d", stride, w);
+    int8_t own_pattern[VSLAM_ORB_PATTERN_BYTES];
+    if (describe) {
+        if (!pattern) { orb_default_pattern(own_pattern); pattern = own_pattern; }
+        else if (!orb_pattern_ok(pattern)) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute: pattern coordinates must lie in [-15, 15]");
+        if (p->edge_threshold < 23) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute: edge_threshold %d < 23 (reach of the rotated pattern)", p->edge_threshold);
+    }
     int nl = p->nlevels;
     while (nl > 0 && (lw[nl - 1] < 2 * p->edge_threshold + 1 || lh[nl - 1] < 2 * p->edge_threshold + 1)) --nl;   // levels with nothing inside the edge
     for (int l = 0; l < nl; ++l) VSLAM_TRY(check_orb_level(ctx, lw[l], lh[l], lw[l], lf[l], p->fast_threshold, p->edge_threshold, p->harris_block));
@@ -1211,15 +1219,26 @@ extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, in
     size_t pyr = 0;
     for (int l = 0; l < nl; ++l) pyr += Arena::pad((size_t)lw[l] * lh[l]);
     const size_t feat_bytes = (size_t)SORT_S * sizeof(vslam_feature);
-    VSLAM_TRY(ws_reserve(ctx, orb_ws_bytes(1) + Arena::pad((size_t)stride * h) + pyr + (size_t)nl * Arena::pad(feat_bytes) + Arena::pad(64)));
+    const size_t desc_bytes = describe ? (size_t)nl * (Arena::pad((size_t)SORT_S * 4) + Arena::pad((size_t)SORT_S * 32)) + Arena::pad((size_t)w * h) + Arena::pad(VSLAM_ORB_PATTERN_BYTES) : 0;
+    VSLAM_TRY(ws_reserve(ctx, orb_ws_bytes(1) + Arena::pad((size_t)stride * h) + pyr + (size_t)nl * Arena::pad(feat_bytes) + Arena::pad(64) + desc_bytes));
     Arena ar(ctx->ws);
     void *dws = ar.take<char>(orb_ws_bytes(1));
     uint8_t *dbase = ar.take<uint8_t>((size_t)stride * h);
     uint8_t *dlev[VSLAM_ORB_MAX_LEVELS];
     vslam_feature *dfeat[VSLAM_ORB_MAX_LEVELS];
+    float *dangle[VSLAM_ORB_MAX_LEVELS];
+    uint8_t *ddesc[VSLAM_ORB_MAX_LEVELS];
     for (int l = 0; l < nl; ++l) dlev[l] = ar.take<uint8_t>((size_t)lw[l] * lh[l]);
     for (int l = 0; l < nl; ++l) dfeat[l] = ar.take<vslam_feature>(SORT_S);
     int32_t *dcount = ar.take<int32_t>(16);
+    uint8_t *dblur = nullptr;
+    int8_t *dpattern = nullptr;
+    if (describe) {
+        for (int l = 0; l < nl; ++l) { dangle[l] = ar.take<float>(SORT_S); ddesc[l] = ar.take<uint8_t>((size_t)SORT_S * 32); }
+        dblur = ar.take<uint8_t>((size_t)w * h);
+        dpattern = ar.take<int8_t>(VSLAM_ORB_PATTERN_BYTES);
+        VSLAM_TRY(h2d(ctx, dpattern, pattern, VSLAM_ORB_PATTERN_BYTES));
+    }
     VSLAM_TRY(h2d(ctx, dbase, gray, (size_t)stride * h));
     for (int l = 0; l < nl; ++l) {
         // level l is resized from level l-1 (level 0 is the image itself)
@@ -1234,6 +1253,10 @@ extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, in
         }
         VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, 0, 1, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
                                    dfeat[l], SORT_S, dcount + l, dws));
+        if (describe) {                                 // the blurred copy is reused level after level (stream order)
+            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, dblur, iw));
+            VSLAM_TRY(launch_orb_describe(ctx, img, is, dblur, iw, iw, ih, dfeat[l], dcount + l, SORT_S, dpattern, dangle[l], ddesc[l]));
+        }
     }
     int32_t hc[16] = {0};
     VSLAM_TRY(d2h(ctx, hc, dcount, sizeof(int32_t) * 16));
@@ -1245,10 +1268,14 @@ extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, in
         if (k < 0) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: level %d has more candidates (or ties at the cut) than %d", l, SORT_S);
         if (level_counts) level_counts[l] = k;
         if (k == 0) continue;
+        if (total + k > cap) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: more than %d keypoints", cap);
         tmp.resize((size_t)k);
         VSLAM_HIP_TRY(ctx, hipMemcpy(tmp.data(), dfeat[l], (size_t)k * sizeof(vslam_feature), hipMemcpyDeviceToHost));
+        if (describe) {
+            VSLAM_HIP_TRY(ctx, hipMemcpy(angle + total, dangle[l], (size_t)k * sizeof(float), hipMemcpyDeviceToHost));
+            VSLAM_HIP_TRY(ctx, hipMemcpy(desc + (size_t)total * 32, ddesc[l], (size_t)k * 32, hipMemcpyDeviceToHost));
+        }
         for (int i = 0; i < k; ++i) {
-            if (total == cap) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: more than %d keypoints", cap);
             vslam_orb_keypoint kp;
             kp.x = l == 0 ? (float)tmp[(size_t)i].x : (float)tmp[(size_t)i].x * ls[l];      // pt *= scale, float
             kp.y = l == 0 ? (float)tmp[(size_t)i].y : (float)tmp[(size_t)i].y * ls[l];
@@ -1258,6 +1285,23 @@ extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, in
     }
     *count = total;
     return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_orb_detect(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *p,
+                                         vslam_orb_keypoint *out, int cap, int32_t *count, int32_t *level_counts)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !p || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect: null pointer or cap < 1");
+    return orb_run(ctx, gray, w, h, stride, p, nullptr, out, nullptr, nullptr, cap, count, level_counts);
+}
+
+extern "C" vslam_status vslam_orb_detect_and_compute(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *p,
+                                                     const int8_t *pattern, vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap,
+                                                     int32_t *count, int32_t *level_counts)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !p || !out || !angle || !desc || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute: null pointer or cap < 1");
+    return orb_run(ctx, gray, w, h, stride, p, pattern, out, angle, desc, cap, count, level_counts);
 }
 
 extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,

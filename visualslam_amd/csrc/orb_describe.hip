@@ -1,0 +1,222 @@
+// Orientation and rBRIEF descriptors of ORB keypoints: the compute() half of cv::ORB as detectAndDrawORB calls
+// it (reference src/imagefeatures.cpp:88-96); the descriptors are what BFMatcher(NORM_HAMMING) consumes at
+// src/SLAM.cpp:222,355.  OpenCV's sources are not part of the reference, so the published algorithm (Rublee et
+// al., "ORB: an efficient alternative to SIFT or SURF", 2011) is restated with OpenCV's documented conventions and
+// the CPU oracle defines the contract; parity unpinned.
+//
+//   blur         7 x 7 Gaussian (sigma 2, reflect-101 borders) of a level image in 8.8 fixed point: weights
+//                {18, 34, 49, 54, 49, 34, 18} / 256 per axis, the row pass exact, the column pass (sum + 2^15) >> 16.
+//   orientation  intensity centroid over the circular patch of radius 15 on the level image (integer moments),
+//                angle in degrees by the odd 7th-order polynomial of cv::fastAtan2.
+//   descriptor   256 tests I(p0) < I(p1) on the blurred level image with the pattern rotated by the angle;
+//                coordinates rounded half to even; bit k of byte i is test 8 i + k.
+//
+// One wavefront per keypoint: two lanes per patch row accumulate the moments, a wave reduction gives the angle in
+// every lane, then lane l evaluates tests 4 l .. 4 l + 3 and pairs of lanes assemble the bytes.  The work is a few
+// hundred scattered byte reads per keypoint out of an image that sits in L2; 10,000 keypoints fill the chip.
+#include "common.hpp"
+#include "orb.hpp"
+
+#include <cmath>
+
+namespace vslam {
+
+namespace {
+
+constexpr int kReach = 23;      // pattern coordinates are limited to |c| <= 15: rotated and rounded they stay within 22
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void gauss7_kernel(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned wt[7] = {18u, 34u, 49u, 54u, 49u, 34u, 18u};
+    int xs[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xs[i] = reflect101(x + i - 3, w);
+    unsigned acc = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const uint8_t *row = src + (size_t)reflect101(y + j - 3, h) * sstride;
+        unsigned hsum = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) hsum += wt[i] * row[xs[i]];
+        acc += wt[j] * hsum;
+    }
+    dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool flat = ax >= ay;
+    const float c = flat ? __fdiv_rn(ay, __fadd_rn(ax, 2.220446049250313e-16f)) : __fdiv_rn(ax, __fadd_rn(ay, 2.220446049250313e-16f));
+    const float c2 = __fmul_rn(c, c);
+    float r = __fadd_rn(__fmul_rn(p7, c2), p5);
+    r = __fadd_rn(__fmul_rn(r, c2), p3);
+    r = __fadd_rn(__fmul_rn(r, c2), p1);
+    r = __fmul_rn(r, c);
+    float a = flat ? r : __fsub_rn(90.f, r);
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+struct DescArgs {
+    const uint8_t *gray, *blur;
+    int w, h, stride, bstride;
+    const vslam_feature *kp;
+    const int32_t *count;
+    int max_count;
+    const int8_t *pattern;
+    float *angle;
+    uint8_t *desc;
+    unsigned long long umax_lo, umax_hi;      // half-widths of patch rows 0..7 and 8..15, a byte each
+};
+
+__global__ __launch_bounds__(256) void orb_describe_kernel(DescArgs a)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(*a.count, a.max_count);
+    if (i >= n) return;
+    const int x = a.kp[i].x, y = a.kp[i].y;
+    if (x < kReach || y < kReach || x >= a.w - kReach || y >= a.h - kReach) {      // patch would leave the image: no orientation, zero descriptor
+        if (lane == 0) a.angle[i] = -1.0f;
+        if (lane < 32) a.desc[(size_t)i * 32 + lane] = 0;
+        return;
+    }
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, av = v < 0 ? -v : v;
+        const int d = (int)(((av < 8 ? a.umax_lo : a.umax_hi) >> (8 * (av & 7))) & 0xffull);
+        const uint8_t *row = a.gray + (size_t)(y + v) * a.stride + x;
+        const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+        int s0 = 0, s1 = 0;
+        for (int u = u0; u <= u1; ++u) { const int p = row[u]; s0 += p; s1 += u * p; }
+        m10 = s1; m01 = v * s0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) a.angle[i] = angle;
+    const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.0));
+    const float ca = (float)cos((double)rad), sa = (float)sin((double)rad);
+    const uint8_t *center = a.blur + (size_t)y * a.bstride + x;
+    const int4 raw = reinterpret_cast<const int4 *>(a.pattern)[lane];      // tests 4 lane .. 4 lane + 3: 16 signed bytes
+    const int words[4] = {raw.x, raw.y, raw.z, raw.w};
+    int nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int val[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float px = (float)(int)(signed char)(words[t] >> (16 * q)), py = (float)(int)(signed char)(words[t] >> (16 * q + 8));
+            const float fx = __fsub_rn(__fmul_rn(px, ca), __fmul_rn(py, sa)), fy = __fadd_rn(__fmul_rn(px, sa), __fmul_rn(py, ca));
+            const int ix = min(max((int)rintf(fx), -(kReach - 1)), kReach - 1), iy = min(max((int)rintf(fy), -(kReach - 1)), kReach - 1);
+            val[q] = center[(ptrdiff_t)iy * a.bstride + ix];
+        }
+        nib |= (val[0] < val[1]) << t;
+    }
+    const int hi = __shfl_down(nib, 1, 64);
+    if (!(lane & 1)) a.desc[(size_t)i * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+// u_max of cv::ORB for a patch of 31: half-width of patch row v, v = 0..15
+void patch_half_widths(unsigned long long *lo, unsigned long long *hi)
+{
+    const int hp = 15;
+    int umax[17] = {0};
+    const int vmax = (int)std::floor(hp * std::sqrt(2.0) / 2 + 1), vmin = (int)std::ceil(hp * std::sqrt(2.0) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = (int)std::nearbyint(std::sqrt((double)hp * hp - (double)v * v));
+    for (int v = hp, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+    *lo = 0; *hi = 0;
+    for (int v = 0; v < 8; ++v) { *lo |= (unsigned long long)umax[v] << (8 * v); *hi |= (unsigned long long)umax[8 + v] << (8 * v); }
+}
+
+}  // namespace
+
+vslam_status launch_gauss7(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    hipLaunchKernelGGL(gauss7_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src, w, h, sstride, dst, dstride);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+vslam_status launch_orb_describe(vslam_ctx *ctx, const uint8_t *gray, int stride, const uint8_t *blur, int bstride, int w, int h,
+                                 const vslam_feature *kp, const int32_t *count, int max_count, const int8_t *pattern,
+                                 float *angle, uint8_t *desc)
+{
+    if (max_count < 1) return VSLAM_OK;
+    DescArgs a;
+    a.gray = gray; a.blur = blur; a.w = w; a.h = h; a.stride = stride; a.bstride = bstride;
+    a.kp = kp; a.count = count; a.max_count = max_count; a.pattern = pattern; a.angle = angle; a.desc = desc;
+    patch_half_widths(&a.umax_lo, &a.umax_hi);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_count + 3) / 4), dim3(256), 0, ctx->stream, a);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+void orb_default_pattern(int8_t *pattern)
+{
+    uint32_t st = 0x34985739u;
+    for (int i = 0; i < 256; ++i) {
+        int c[4];
+        do {
+            for (int k = 0; k < 4; ++k) { st = st * 1664525u + 1013904223u; c[k] = (int)((st >> 16) % 27u) - 13; }
+        } while (c[0] == c[2] && c[1] == c[3]);
+        for (int k = 0; k < 4; ++k) pattern[4 * i + k] = (int8_t)c[k];
+    }
+}
+
+bool orb_pattern_ok(const int8_t *pattern)
+{
+    for (int i = 0; i < VSLAM_ORB_PATTERN_BYTES; ++i)
+        if (pattern[i] < -15 || pattern[i] > 15) return false;
+    return true;
+}
+
+}  // namespace vslam
+
+using namespace vslam;
+
+extern "C" vslam_status vslam_orb_default_pattern(int8_t *pattern)
+{
+    if (!pattern) return VSLAM_ERR_ARG;
+    orb_default_pattern(pattern);
+    return VSLAM_OK;
+}
+
+extern "C" vslam_status vslam_gaussian_blur7_dev(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!src || !dst) return fail(ctx, VSLAM_ERR_ARG, "gaussian_blur7: null pointer");
+    if (w < 1 || h < 1 || sstride < w || dstride < w || w > 65535 || h > 65535)
+        return fail(ctx, VSLAM_ERR_SHAPE, "gaussian_blur7: %dx%d (strides %d, %d)", w, h, sstride, dstride);
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_gauss7(ctx, src, w, h, sstride, dst, dstride);
+}
+
+extern "C" vslam_status vslam_orb_describe_level_dev(vslam_ctx *ctx, const uint8_t *gray, int stride, const uint8_t *blurred, int bstride,
+                                                     int w, int h, const vslam_feature *keypoints, const int32_t *count, int max_count,
+                                                     const int8_t *pattern, float *angle, uint8_t *desc)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !blurred || !keypoints || !count || !pattern || !angle || !desc) return fail(ctx, VSLAM_ERR_ARG, "orb_describe: null pointer");
+    if (w < 1 || h < 1 || stride < w || bstride < w || max_count < 0) return fail(ctx, VSLAM_ERR_SHAPE, "orb_describe: %dx%d (strides %d, %d), %d keypoints", w, h, stride, bstride, max_count);
+    if (reinterpret_cast<uintptr_t>(pattern) & 15) return fail(ctx, VSLAM_ERR_ARG, "orb_describe: the pattern must be 16-byte aligned");
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_orb_describe(ctx, gray, stride, blurred, bstride, w, h, keypoints, count, max_count, pattern, angle, desc);
+}
