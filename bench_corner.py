@@ -105,6 +105,50 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
                     "roofline": {"bound": "hbm", "kernel": "fast9_tile_kernel + sort/merge/emit", "achieved": falg / (fast_ms * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": falg / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                  "algorithmic_bytes_per_step": falg}}
+    # ORB as the reference configures it: level-0 keypoints (FAST -> edge -> 2n by FAST score -> Harris at the corners
+    # -> n best) for all frames in one call, then blur + orientation + descriptors frame by frame; and the whole
+    # 8-level pyramid of one host frame through the host-pointer entry (PCIe and the level loop included)
+    try:
+        n0 = int(api.orb_level_plan(api.orb_params(), W, H)[2][0])
+        ocap = 16384
+        oout = torch.zeros((F, ocap, 3), dtype=torch.int32, device=dev)
+        ocnt = torch.zeros(F, dtype=torch.int32, device=dev)
+        oblur = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+        oang = torch.zeros((F, ocap), dtype=torch.float32, device=dev)
+        odesc = torch.zeros((F, ocap, 32), dtype=torch.uint8, device=dev)
+        opat = torch.tensor(api.orb_default_pattern(), device=dev)
+
+        def orb_detect_step():
+            api.orb_detect_level_batch_dev(ctx, frames, W, H, W, W * H, F, n0, oout, ocap, ocnt)
+
+        def orb_describe_step():
+            for i in range(F):
+                api.gaussian_blur7_dev(ctx, frames[i], oblur)
+                api.orb_describe_level_dev(ctx, frames[i], oblur, oout[i], ocnt[i:i + 1], n0 + 64, opat, oang[i], odesc[i])
+
+        orb = {}
+        for name, fn, reps in (("detect_level0", orb_detect_step, 10), ("blur_orient_describe_level0", orb_describe_step, 3)):
+            fn()
+            torch.cuda.synchronize()
+            f0.record(stream)
+            for _ in range(reps):
+                fn()
+            f1.record(stream)
+            torch.cuda.synchronize()
+            ms = f0.elapsed_time(f1) / reps
+            orb[name] = {"ms_per_step": ms, "frames_per_s": F / (ms * 1e-3)}
+        orb["mean_keypoints_level0"] = float(ocnt.clamp(min=0).float().mean().item())
+        hctx = api.Context(dev.index or 0)
+        api.orb_detect_and_compute(hctx, base[0])
+        t0 = time.perf_counter()
+        kpo, ango, desco, levo = api.orb_detect_and_compute(hctx, base[0])
+        orb["host_frame_8_levels_ms"] = (time.perf_counter() - t0) * 1e3
+        orb["host_frame_keypoints"] = int(kpo.size)
+        hctx.close()
+        res["orb"] = orb
+        del oout, ocnt, oblur, oang, odesc
+    except Exception as exc:                # reported, not fatal: the headline metric above stands on its own
+        res["orb"] = {"error": repr(exc)}
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as orc
         t0 = time.perf_counter()

@@ -364,8 +364,9 @@ inline void matchHamming(const uint8_t *query, int nq, const uint8_t *train, int
         if (idx[(size_t)q] >= 0) matches.push_back(Match{q, idx[(size_t)q], (float)dist[(size_t)q]});
 }
 
-// Opt-in: solve the trust-region subproblems of measurementUpdateIEKF on the device from Cholesky
-// factors instead of the reference's host eigendecomposition (same iterates; see vslam_hip.h).
+// measurementUpdateIEKF solves its trust-region subproblems on the device from Cholesky factors by default
+// (falling back to the reference's host eigendecomposition when a Hessian is not positive definite; see
+// vslam_hip.h).  useDeviceTrustRegion(false) selects the eigendecomposition route outright.
 inline void useDeviceTrustRegion(bool on) { check(vslam_ctx_set_trs_solver(context(), on ? VSLAM_TRS_CHOLESKY : VSLAM_TRS_EIG)); }
 
 // ---- data association -------------------------------------------------------
