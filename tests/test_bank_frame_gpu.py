@@ -1,7 +1,8 @@
 """One frame of a bank of device-resident filters through the *_batch_dev entry points, stage by stage:
 time update -> predicted measurement density -> data association -> measurement update -> landmark removal ->
 landmark initialisation.  Every stage consumes the previous stage's device tensors as they are (the layouts must
-fit together) and is checked against the single-filter host entry point fed with the same inputs."""
+fit together) and is checked against the single-filter host entry point and against the CPU restatement of the
+reference, both fed with the same inputs."""
 import numpy as np
 import pytest
 
@@ -15,8 +16,9 @@ def _cm(t):
     return t.cpu().numpy().transpose(0, 2, 1)
 
 
-def test_frame_of_a_bank(ctx, gcam):
+def test_frame_of_a_bank(ctx, gcam, ocam):
     import torch
+    from oracle import pyoracle as orc
     from visualslam_amd import api, synthetic as syn
     B, L = 3, 12
     n, m = 12 + 3 * L, 2 * L
@@ -36,6 +38,8 @@ def test_frame_of_a_bank(ctx, gcam):
         for b in range(B):
             wm, wS = api.time_update(tctx, scs[b].x, scs[b].S, PT, OT, 1 / 30)
             assert rel_err(mu1[b].cpu().numpy(), wm) < 1e-11 and rel_err(_cm(S1)[b], wS) < 1e-9
+            om, oS = orc.time_update(scs[b].x, scs[b].S, PT, OT, 1 / 30)
+            assert rel_err(mu1[b].cpu().numpy(), om) < 1e-11 and rel_err(_cm(S1)[b], oS) < 1e-9
 
         # 2. predicted measurement density
         muy = torch.empty((B, m), dtype=torch.float64, device=dev)
@@ -48,6 +52,10 @@ def test_frame_of_a_bank(ctx, gcam):
             wy, wSy, wc = api.affine_bundle(tctx, gcam, h_mu1[b], h_S1[b])
             assert np.array_equal(code[b].cpu().numpy(), wc)
             assert rel_err(muy[b].cpu().numpy(), wy) < 1e-11 and rel_err(_cm(Syy)[b], wSy) < 1e-9
+            oh, oSR, oC, ocode = orc.bundle_measure(h_mu1[b], ocam)
+            oSy = orc.affine_sqrt(h_S1[b], oC, oSR)
+            assert np.array_equal(code[b].cpu().numpy(), ocode)
+            assert rel_err(muy[b].cpu().numpy(), oh) < 1e-11 and rel_err(_cm(Syy)[b], np.triu(oSy)) < 1e-9
 
         # 3. data association against features = predicted pixels + noise, shuffled, plus two strays
         rng = np.random.default_rng(1)
@@ -68,6 +76,8 @@ def test_frame_of_a_bank(ctx, gcam):
             ws, widx = api.snn_density(tctx, h_muy[b], h_Syy[b], feats[b].T, gcam.width, gcam.height)
             assert h_idx[b].tolist() == widx.tolist()
             assert abs(float(sur[b]) - ws) <= 1e-9 * abs(ws)
+            os_, oidx = orc.snn_density(h_muy[b], h_Syy[b], feats[b].T, gcam.width, gcam.height)
+            assert h_idx[b].tolist() == list(oidx) and abs(float(sur[b]) - os_) <= 1e-9 * abs(os_)
             assert (h_idx[b] >= 0).sum() >= L - 2                           # nearly every landmark finds its feature
 
         # 4. measurement update with the associated features
@@ -89,6 +99,8 @@ def test_frame_of_a_bank(ctx, gcam):
             assert rel_err(h_mu2[b], wm) < 1e-7
             assert rel_err(h_S2[b].T @ h_S2[b], wS.T @ wS) < 1e-6
             assert not np.tril(h_S2[b], -1).any()
+            _, om, oS, _, _ = orc.measurement_update_iekf(h_mu1[b], h_S1[b], ys[b], vis[b], ocam, 7.0)
+            assert rel_err(h_mu2[b], om) < 1e-7 and rel_err(h_S2[b].T @ h_S2[b], oS.T @ oS) < 1e-6
 
         # 5. every filter drops a landmark of its own
         js = [0, L - 1, 5]
@@ -101,6 +113,9 @@ def test_frame_of_a_bank(ctx, gcam):
         for b in range(B):
             wm, wS = api.remove_landmark(tctx, h_mu2[b], h_S2[b], js[b])
             assert np.array_equal(mu3[b].cpu().numpy(), wm) and np.array_equal(_cm(S3)[b], wS)
+            om, oS = orc.remove_landmark(h_mu2[b], h_S2[b], js[b])
+            assert np.array_equal(mu3[b].cpu().numpy(), om)
+            assert rel_err(np.abs(_cm(S3)[b]), np.abs(np.triu(oS))) < 1e-9      # rows with an exact-zero pivot get their sign from rounding
 
         # 6. and takes in two new keypoints
         M = 2

@@ -97,6 +97,7 @@ def test_remove_landmark_bank(ctx):
     """A bank of filters, each dropping its own landmark (first, last, in between), one with an index outside
     the map: results equal the single-filter entry bit for bit, the bad one is reported and left untouched."""
     import torch
+    from oracle import pyoracle as orc
     from visualslam_amd import api
     n, B = 162, 6
     L = (n - 12) // 3
@@ -124,6 +125,9 @@ def test_remove_landmark_bank(ctx):
         mu0, S0 = api.remove_landmark(ctx, mus[b], np.triu(Ss[b]), js[b])
         assert np.array_equal(mo[b], mu0)
         assert np.array_equal(So[b].T, S0)
+        mu1, S1 = orc.remove_landmark(mus[b], np.triu(Ss[b]), js[b])        # and the CPU restatement (dense factor: signs are decided)
+        assert np.array_equal(mo[b], mu1)
+        assert rel_err(So[b].T, np.triu(S1)) < 1e-9
 
 
 def test_remove_landmark_general_square_factor(ctx):
