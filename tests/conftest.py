@@ -39,8 +39,12 @@ def gcam():
 
 @pytest.fixture(scope="session")
 def ctx():
+    """The library context shared by the GPU tests.  It runs on torch's current stream, so that tensors the tests
+    build with torch (fills, copies) are ordered before the library's kernels without a device-wide synchronisation;
+    tests that want a stream of the library's own create their context themselves."""
+    import torch
     from visualslam_amd import api
-    c = api.Context(0)
+    c = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     yield c
     c.close()
 

@@ -134,6 +134,36 @@ def test_batched_device_entry(ctx, gcam, ocam):
     tctx.close()
 
 
+def test_context_with_a_stream_of_its_own(gcam, ocam):
+    """A context created without a stream owns a non-blocking one: the caller orders its own device work around the
+    library's (here: a device-wide synchronisation before, the context's synchronise after)."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    L = 40
+    n = 12 + 3 * L
+    sc = syn.Scene(L, 77, dense_S=False)
+    dev = torch.device("cuda:0")
+    x = torch.tensor(sc.x[None], device=dev)
+    y = torch.tensor(sc.y[None], device=dev)
+    vis = torch.tensor(sc.visible[None], device=dev)
+    val = torch.full((1,), float("nan"), dtype=torch.float64, device=dev)
+    g = torch.full((1, n), float("nan"), dtype=torch.float64, device=dev)
+    H = torch.full((1, n, n), float("nan"), dtype=torch.float64, device=dev)
+    own = api.Context(0)
+    try:
+        torch.cuda.synchronize()
+        api.point_loglik_batch_dev(own, gcam, n, x, y, vis, 7.0, val, g, H)
+        own.synchronize()
+        v0, g0, H0, _ = orc.point_loglik_analytic(sc.x, sc.y, sc.visible, ocam, 7.0)
+        assert abs(val[0].item() - v0) <= TOL * abs(v0)
+        assert rel_err(g[0].cpu().numpy(), g0) <= TOL and rel_err(H[0].cpu().numpy().T, H0) <= TOL
+        v1, g1, H1, _ = api.point_loglik(own, gcam, sc.x, sc.y, sc.visible, 7.0)       # host-pointer entry on the same context
+        assert abs(v1 - v0) <= TOL * abs(v0) and rel_err(H1, H0) <= TOL
+    finally:
+        own.close()
+
+
 def test_shape_errors(ctx, gcam):
     from visualslam_amd import api
     with pytest.raises(api.VslamError):
