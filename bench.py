@@ -130,10 +130,19 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; libvslam_hip has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal of the multi-rank code path on a box with fewer GPUs than ranks: VSLAM_BENCH_SHARE_GPU=1 puts every
+    # rank on GPU 0 and VSLAM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  The numbers
+    # of such a run mean nothing; the line says so in "rehearsal".
+    share_gpu = os.environ.get("VSLAM_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -155,7 +164,7 @@ def main():
     code = torch.empty((B, L), dtype=torch.int32, device=dev)
 
     stream = torch.cuda.current_stream()
-    ctx = api.Context(local_rank, stream=stream.cuda_stream)
+    ctx = api.Context(dev_index, stream=stream.cuda_stream)
     cam = api.camera_from_xml(syn.CAMERA_XML)
 
     def step():
@@ -180,28 +189,36 @@ def main():
     # ... with the payload a bank of filters hands over: posterior mean + packed upper-triangular factor per filter
     # (a small bank per rank runs one lock-step measurement update here, outside the timed region)
     filt_msg = None
+    nb_f = 16
+    f_mo = torch.zeros((nb_f, n), dtype=torch.float64, device=dev)
+    f_So = torch.zeros((nb_f, n, n), dtype=torch.float64, device=dev)
+    f_err, f_npd = None, -1
     try:
-        nb_f = 16
         scs = [syn.Scene(L, sharding.instance_seed(9500, rank, i), dense_S=True) for i in range(4)]
         f_mu = torch.tensor(np.stack([scs[i % 4].x for i in range(nb_f)]), device=dev)
         f_S = torch.tensor(np.stack([np.ascontiguousarray(scs[i % 4].S.T) for i in range(nb_f)]), device=dev)
         f_y = torch.tensor(np.stack([scs[i % 4].y for i in range(nb_f)]), device=dev)
         f_v = torch.tensor(np.stack([scs[i % 4].visible for i in range(nb_f)]), device=dev)
-        f_mo, f_So = torch.empty_like(f_mu), torch.empty_like(f_S)
         _, _, f_status = api.measurement_update_iekf_batch_dev(ctx, cam, f_mu, f_S, f_y, f_v, SIGMA, f_mo, f_So)
-        t_g = time.perf_counter()
-        msg = sharding.gather_filter_results_to_root(f_mo, f_So)
-        torch.cuda.synchronize()
-        t_g = time.perf_counter() - t_g
-        if msg is not None:
-            mu_all, S_all = sharding.unpack_filter_results(msg, n)
-            filt_msg = {"filters_per_rank": nb_f, "doubles_per_filter": int(msg.shape[1]), "bytes_per_rank": int(msg.shape[1]) * 8 * nb_f,
-                        "gather_ms": t_g * 1e3, "filters_on_root": int(msg.shape[0]),
-                        "own_block_round_trip_exact": bool(torch.equal(mu_all[:nb_f], f_mo) and torch.equal(S_all[:nb_f], torch.tril(f_So))),
-                        "not_positive_definite_on_rank0": int(f_status.sum())}
-        del f_mu, f_S, f_y, f_v, f_mo, f_So, msg
+        f_npd = int(f_status.sum())
+        del f_mu, f_S, f_y, f_v
     except Exception as exc:      # the headline measurement above must not be lost to a failure here
-        filt_msg = {"error": repr(exc)}
+        f_err = repr(exc)
+    # every rank takes part in the gather whatever happened to its own update: a rank that skipped the collective
+    # would leave the others waiting
+    t_g = time.perf_counter()
+    msg = sharding.gather_filter_results_to_root(f_mo, f_So)
+    torch.cuda.synchronize()
+    t_g = time.perf_counter() - t_g
+    if msg is not None:
+        mu_all, S_all = sharding.unpack_filter_results(msg, n)
+        filt_msg = {"filters_per_rank": nb_f, "doubles_per_filter": int(msg.shape[1]), "bytes_per_rank": int(msg.shape[1]) * 8 * nb_f,
+                    "gather_ms": t_g * 1e3, "filters_on_root": int(msg.shape[0]),
+                    "own_block_round_trip_exact": bool(torch.equal(mu_all[:nb_f], f_mo) and torch.equal(S_all[:nb_f], torch.tril(f_So))),
+                    "not_positive_definite_on_rank0": f_npd}
+        if f_err:
+            filt_msg["error_on_rank0"] = f_err
+    del f_mo, f_So, msg
 
     # the two kernels of the call apart (outside the timed region): events inside the library, on its stream
     ctx.set_kernel_timing(True)
@@ -271,6 +288,8 @@ def main():
             "single_instance_updates_per_s": L / (single_us * 1e-6),
             "host": host_info(),
         }
+        if share_gpu or backend != "nccl":
+            out["rehearsal"] = "ranks share GPU 0 = %s, backend %s: exercises the multi-rank code path only, the numbers are not a measurement" % (share_gpu, backend)
         if corner is not None:
             out["corner"] = corner
         if dense is not None:
