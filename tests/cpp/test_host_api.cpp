@@ -409,6 +409,40 @@ static void test_detect_corners()
     CHECK_TRUE(near == 4);
 }
 
+static void test_detect_and_compute_orb()
+{
+    // a field of bright blocks on a dark ground: corners well inside the 75-pixel edge
+    const int w = 640, h = 480;
+    std::vector<uint8_t> img((size_t)w * h, 40);
+    for (int by = 0; by < 5; ++by)
+        for (int bx = 0; bx < 7; ++bx)
+            for (int y = 0; y < 30; ++y)
+                for (int x = 0; x < 30; ++x) img[(size_t)(100 + 60 * by + y) * w + 100 + 60 * bx + x] = (uint8_t)(150 + 10 * ((bx + by) % 5));
+    // a little noise: on a noiseless pattern neighbouring corner pixels tie in FAST score and suppress one another
+    uint32_t st = 12345u;
+    for (uint8_t &px : img) { st = st * 1664525u + 1013904223u; px = (uint8_t)(px + (int)((st >> 24) % 7u) - 3); }
+    std::vector<OrbKeypoint> kp;
+    std::vector<float> ang;
+    std::vector<uint8_t> desc;
+    detectAndComputeORB(img.data(), w, h, w, 500, kp, ang, desc);
+    CHECK_TRUE(kp.size() >= 100 && ang.size() == kp.size() && desc.size() == 32 * kp.size());
+    int level0 = 0, any_bits = 0;
+    for (size_t i = 0; i < kp.size(); ++i) {
+        CHECK_TRUE(ang[i] >= 0.0f && ang[i] <= 360.0f);
+        CHECK_TRUE(kp[i].octave >= 0 && kp[i].octave < 8 && kp[i].x >= 75.0f && kp[i].x < (float)(w - 75));
+        if (i > 0 && kp[i].octave == kp[i - 1].octave) CHECK_TRUE(kp[i - 1].response >= kp[i].response);
+        level0 += kp[i].octave == 0;
+        for (int b = 0; b < 32; ++b) any_bits |= desc[32 * i + b];
+    }
+    if (!(level0 >= 10 && any_bits != 0)) std::printf("orb: %zu keypoints, %d on level 0, descriptor bits or-ed %d\n", kp.size(), level0, any_bits);
+    CHECK_TRUE(level0 >= 10 && any_bits != 0);
+    // a descriptor matches itself at distance 0 and the matcher finds it
+    std::vector<Match> matches;
+    matchHamming(desc.data(), (int)kp.size(), desc.data(), (int)kp.size(), 32, matches);
+    CHECK_TRUE(matches.size() == kp.size());
+    for (const Match &mt : matches) CHECK_TRUE(mt.distance == 0.0f);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: %s <camera.xml>\n", argv[0]); return 2; }
@@ -420,6 +454,7 @@ int main(int argc, char **argv)
         test_point_log_likelihood(argv[1]);
         test_measurement_update(argv[1]);
         test_detect_corners();
+        test_detect_and_compute_orb();
         test_data_association(argv[1]);
         test_time_update();
         test_landmark_bookkeeping();

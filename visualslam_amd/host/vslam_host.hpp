@@ -11,7 +11,7 @@
 //   conditionGaussianOnMarginal                   src/gaussian.cpp:19-36
 //   SlamProcessModel, timeUpdateContinuous        src/model.hpp:36-41, src/gaussian.hpp:337-383
 //   removeBadLandmarks, matchHamming (BFMatcher)  src/SLAM.cpp:796-820, 222,355
-//   Feature, detectCorners                        src/imagefeatures.h:15-19,37
+//   Feature, detectCorners, detectAndComputeORB   src/imagefeatures.h:15-19,37, src/imagefeatures.cpp:73-96
 //   chi2inv, normcdf                              src/utility.cpp:13-24
 //   individualCompatibility, jointCompatibility,
 //   snn                                           src/dataAssociation.h:10-12
@@ -424,6 +424,28 @@ inline int detectCorners(const uint8_t *gray, int width, int height, int stride,
     int32_t count = 0;
     check(vslam_corner_detect(context(), gray, width, height, stride, &p, detector, keypoints.data(), maxNumFeatures, &count));
     keypoints.resize((size_t)count);
+    return 0;
+}
+
+// ---- ORB front end ---------------------------------------------------------------
+// detectAndDrawORB's orb->detect + orb->compute (src/imagefeatures.cpp:73-96) without the drawing: keypoints of all
+// pyramid levels (level 0 first, by response within a level), their angles in degrees and 32-byte descriptors
+// (row i of `descriptors` belongs to keypoints[i]; the layout of a continuous CV_8U cv::Mat with 32 columns).
+// `pattern` is cv::ORB's 256 x 4 test table as signed bytes, or nullptr for the library's own table.
+using OrbKeypoint = vslam_orb_keypoint;        // {x, y, response, octave}
+inline int detectAndComputeORB(const uint8_t *gray, int width, int height, int stride, int maxNumFeatures,
+                               std::vector<OrbKeypoint> &keypoints, std::vector<float> &angles, std::vector<uint8_t> &descriptors,
+                               const int8_t *pattern = nullptr)
+{
+    vslam_orb_params p{};
+    p.nfeatures = maxNumFeatures; p.scale_factor = 1.2f; p.nlevels = 8; p.edge_threshold = 75; p.fast_threshold = 20;
+    p.harris_block = 7; p.harris_k = 0.04f;
+    const int cap = 2 * maxNumFeatures + 1024;             // ties at a level's cut are kept, as cv::ORB keeps them
+    keypoints.resize((size_t)cap); angles.resize((size_t)cap); descriptors.resize((size_t)cap * 32);
+    int32_t count = 0;
+    check(vslam_orb_detect_and_compute(context(), gray, width, height, stride, &p, pattern, keypoints.data(), angles.data(),
+                                       descriptors.data(), cap, &count, nullptr));
+    keypoints.resize((size_t)count); angles.resize((size_t)count); descriptors.resize((size_t)count * 32);
     return 0;
 }
 
