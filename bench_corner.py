@@ -138,6 +138,25 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
             ms = f0.elapsed_time(f1) / reps
             orb[name] = {"ms_per_step": ms, "frames_per_s": F / (ms * 1e-3)}
         orb["mean_keypoints_level0"] = float(ocnt.clamp(min=0).float().mean().item())
+        # the whole front end, all eight levels, keypoints + angles + descriptors, one call for the batch
+        bcap = 12288
+        bout = torch.zeros((F, bcap, 4), dtype=torch.int32, device=dev)
+        bcnt = torch.zeros(F, dtype=torch.int32, device=dev)
+        bang = torch.zeros((F, bcap), dtype=torch.float32, device=dev)
+        bdesc = torch.zeros((F, bcap, 32), dtype=torch.uint8, device=dev)
+        for name, kw in (("all_levels_detect", {}), ("all_levels_detect_and_describe", {"angle": bang, "desc": bdesc})):
+            api.orb_detect_and_compute_batch_dev(ctx, frames, bout, bcnt, **kw)
+            torch.cuda.synchronize()
+            f0.record(stream)
+            for _ in range(3):
+                api.orb_detect_and_compute_batch_dev(ctx, frames, bout, bcnt, **kw)
+            f1.record(stream)
+            torch.cuda.synchronize()
+            ms = f0.elapsed_time(f1) / 3
+            orb[name] = {"ms_per_step": ms, "frames_per_s": F / (ms * 1e-3)}
+        orb["mean_keypoints_all_levels"] = float(bcnt.clamp(min=0).float().mean().item())
+        orb["frames_over_capacity"] = int((bcnt < 0).sum().item())
+        del bout, bcnt, bang, bdesc
         hctx = api.Context(dev.index or 0)
         api.orb_detect_and_compute(hctx, base[0])
         t0 = time.perf_counter()

@@ -481,6 +481,14 @@ vslam_status vslam_orb_describe_level_dev(vslam_ctx *ctx, const uint8_t *gray, i
 vslam_status vslam_orb_detect_and_compute(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, const vslam_orb_params *params,
                                           const int8_t *pattern, vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap,
                                           int32_t *count, int32_t *level_counts);
+/* The same for a batch of device-resident frames (frame f at gray + f*stride_frame), everything on the device and
+ * queued on the context's stream: out + f*cap, angle + f*cap, desc + f*cap*32 (angle and desc both NULL: keypoints
+ * only), count[f] (-1: a level overflowed or the frame has more than cap keypoints), level_counts[f][nlevels]
+ * (optional).  pattern: device table, 16-byte aligned, or NULL for the library's own. */
+vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                                    int frames, const vslam_orb_params *params, const int8_t *pattern,
+                                                    vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap, int32_t *count,
+                                                    int32_t *level_counts);
 
 #ifdef __cplusplus
 }

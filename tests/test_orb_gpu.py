@@ -263,3 +263,50 @@ def test_detect_and_compute_rejects_a_bad_pattern(ctx):
     pat[17] = 16
     with pytest.raises(api.VslamError):
         api.orb_detect_and_compute(ctx, syn.frame(1), api.orb_params(nfeatures=100), pattern=pat)
+
+
+@pytest.mark.parametrize("describe", [True, False])
+def test_batch_of_frames_equals_the_single_frame_entry(ctx, describe):
+    """vslam_orb_detect_and_compute_batch_dev on three different device-resident frames (one of them with a row
+    stride larger than its width) against the host-pointer entry frame by frame: records, angles, descriptors and
+    per-level counts identical; and the single-frame entry is the one checked against the oracle above."""
+    import torch
+    from visualslam_amd import api, synthetic as syn
+    params = api.orb_params(nfeatures=1500)
+    imgs = [syn.frame(30), syn.frame(31)[:, ::-1].copy(), np.roll(syn.frame(32), 40, axis=0)]
+    F, (h, w) = len(imgs), imgs[0].shape
+    dev = torch.device("cuda:0")
+    buf = torch.zeros((F, h, w + 64), dtype=torch.uint8, device=dev)          # padded rows: stride != width
+    for f, im in enumerate(imgs):
+        buf[f, :, :w] = torch.tensor(im, device=dev)
+    frames = buf[:, :, :w]
+    cap = 4096
+    out = torch.full((F, cap, 4), -1, dtype=torch.int32, device=dev)
+    cnt = torch.full((F,), -7, dtype=torch.int32, device=dev)
+    lev = torch.full((F, params.nlevels), -7, dtype=torch.int32, device=dev)
+    angle = torch.zeros((F, cap), dtype=torch.float32, device=dev) if describe else None
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=dev) if describe else None
+    api.orb_detect_and_compute_batch_dev(ctx, frames, out, cnt, params, angle=angle, desc=desc, level_counts=lev)
+    ctx.synchronize()
+    rec = out.cpu().numpy().view(api.ORB_KEYPOINT_DTYPE).reshape(F, cap)
+    for f, im in enumerate(imgs):
+        kp, ang, dsc, lv = api.orb_detect_and_compute(ctx, im, params)
+        k = int(cnt[f])
+        assert k == kp.size > 300 and lev[f].cpu().numpy().tolist() == [int(v) for v in lv]
+        assert np.array_equal(rec[f, :k], kp)
+        assert (out[f, k:].cpu().numpy() == -1).all()                         # nothing written past the count
+        if describe:
+            assert np.array_equal(angle[f, :k].cpu().numpy().view(np.uint32), ang.view(np.uint32))
+            assert np.array_equal(desc[f, :k].cpu().numpy(), dsc)
+
+
+def test_batch_reports_a_frame_that_does_not_fit(ctx):
+    import torch
+    from visualslam_amd import api, synthetic as syn
+    params = api.orb_params(nfeatures=1500)
+    frames = torch.tensor(np.stack([syn.frame(30), np.full((1080, 1920), 90, dtype=np.uint8)]), device="cuda:0")
+    out = torch.zeros((2, 100, 4), dtype=torch.int32, device="cuda:0")        # room for 100 keypoints only
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    api.orb_detect_and_compute_batch_dev(ctx, frames, out, cnt, params)
+    ctx.synchronize()
+    assert cnt.cpu().numpy().tolist() == [-1, 0]                              # too many for cap; a flat frame has none

@@ -150,6 +150,7 @@ def _declare(L):
         "vslam_gaussian_blur7_dev": [_vp, _vp, _i, _i, _i, _vp, _i],
         "vslam_orb_describe_level_dev": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
         "vslam_orb_detect_and_compute": [_vp, _vp, _i, _i, _i, C.POINTER(OrbParams), _vp, _vp, _vp, _vp, _i, _vp, _vp],
+        "vslam_orb_detect_and_compute_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(OrbParams), _vp, _vp, _vp, _vp, _i, _vp, _vp],
         "vslam_corner_detect_batch_dev": [_vp, _vp, _i, _i, _i, _sz, _i, C.POINTER(CornerParams), _i, _vp, _i, _vp],
     }
     for name, args in sig.items():

@@ -495,6 +495,17 @@ def orb_detect_and_compute(ctx, gray, params=None, pattern=None, cap=32768):
     return out[:k].copy(), angle[:k].copy(), desc[:k].copy(), lev
 
 
+def orb_detect_and_compute_batch_dev(ctx, frames, out, count, params=None, pattern=None, angle=None, desc=None, level_counts=None):
+    """The whole ORB front end for device-resident frames: frames (F, h, w) uint8; out (F, cap, 4) int32 holding the
+    ORB_KEYPOINT records (x, y, response as float bits, octave); count (F,) int32; optional angle (F, cap) float32 with
+    desc (F, cap, 32) uint8, level_counts (F, nlevels) int32, pattern int8[1024] on the device.  Queued, not synchronised."""
+    params = orb_params() if params is None else params
+    F, h, w = frames.shape
+    check(ctx._L.vslam_orb_detect_and_compute_batch_dev(ctx.ptr, _tp(frames), w, h, frames.stride(1), frames.stride(0), F, C.byref(params),
+                                                        _tp(pattern), _tp(out), _tp(angle), _tp(desc), out.shape[1], _tp(count),
+                                                        _tp(level_counts)), ctx.ptr)
+
+
 def gaussian_blur7_dev(ctx, src, dst):
     """src and dst (h, w) uint8 torch tensors on the GPU, rows contiguous."""
     check(ctx._L.vslam_gaussian_blur7_dev(ctx.ptr, _tp(src), src.shape[1], src.shape[0], src.stride(0), _tp(dst), dst.stride(0)), ctx.ptr)

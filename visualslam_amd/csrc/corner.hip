@@ -814,10 +814,13 @@ __global__ void orb_emit_kernel(const uint64_t *cand, const int32_t *kept, int c
 
 // dst(x, y) of the bilinear resize used between pyramid levels: source position (x + 1/2) sw / dw - 1/2 in units of
 // 1/2048 pixel (integer arithmetic throughout, so the CPU oracle and this kernel agree bit for bit), clamped to the image.
-__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh, int dstride)
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw,
+                                                              int dh, int dstride, size_t dframe)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dw) return;
+    src += (size_t)blockIdx.z * sframe;                       // frame blockIdx.z of a batch
+    dst += (size_t)blockIdx.z * dframe;
     long long X = ((long long)(2 * x + 1) * sw * 1024) / dw - 1024, Y = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
     X = X < 0 ? 0 : (X > (long long)(sw - 1) * 2048 ? (long long)(sw - 1) * 2048 : X);
     Y = Y < 0 ? 0 : (Y > (long long)(sh - 1) * 2048 ? (long long)(sh - 1) * 2048 : Y);
@@ -1163,7 +1166,7 @@ extern "C" vslam_status vslam_resize_bilinear_dev(vslam_ctx *ctx, const uint8_t 
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw || dstride < dw || sw > 65535 || sh > 65535 || dw > 65535 || dh > 65535)
         return fail(ctx, VSLAM_ERR_SHAPE, "resize: %dx%d (stride %d) -> %dx%d (stride %d)", sw, sh, sstride, dw, dh, dstride);
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, ctx->stream, src, sw, sh, sstride, dst, dw, dh, dstride);
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, ctx->stream, src, sw, sh, sstride, (size_t)0, dst, dw, dh, dstride, (size_t)0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -1247,15 +1250,15 @@ static vslam_status orb_run(vslam_ctx *ctx, const uint8_t *gray, int w, int h, i
         if (l > 0) {
             const uint8_t *prev = l == 1 ? dbase : dlev[l - 1];
             const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lw[l - 1];
-            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l]), dim3(256), 0, ctx->stream, prev, pw, ph, ps, dlev[l], lw[l], lh[l], lw[l]);
+            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l]), dim3(256), 0, ctx->stream, prev, pw, ph, ps, (size_t)0, dlev[l], lw[l], lh[l], lw[l], (size_t)0);
             VSLAM_HIP_TRY(ctx, hipGetLastError());
             img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lw[l];
         }
         VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, 0, 1, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
                                    dfeat[l], SORT_S, dcount + l, dws));
         if (describe) {                                 // the blurred copy is reused level after level (stream order)
-            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, dblur, iw));
-            VSLAM_TRY(launch_orb_describe(ctx, img, is, dblur, iw, iw, ih, dfeat[l], dcount + l, SORT_S, dpattern, dangle[l], ddesc[l]));
+            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, 0, dblur, iw, 0, 1));
+            VSLAM_TRY(launch_orb_describe(ctx, img, is, 0, dblur, iw, 0, iw, ih, 1, dfeat[l], dcount + l, SORT_S, dpattern, dangle[l], ddesc[l]));
         }
     }
     int32_t hc[16] = {0};
@@ -1302,6 +1305,149 @@ extern "C" vslam_status vslam_orb_detect_and_compute(vslam_ctx *ctx, const uint8
     if (!ctx) return VSLAM_ERR_ARG;
     if (!gray || !p || !out || !angle || !desc || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute: null pointer or cap < 1");
     return orb_run(ctx, gray, w, h, stride, p, pattern, out, angle, desc, cap, count, level_counts);
+}
+
+// ---- the whole ORB front end for a batch of device-resident frames ----
+struct OrbPackArgs {
+    const vslam_feature *feat[VSLAM_ORB_MAX_LEVELS];      // [frames][cap_l] per level
+    const float *angle[VSLAM_ORB_MAX_LEVELS];
+    const uint8_t *desc[VSLAM_ORB_MAX_LEVELS];
+    int cap_l[VSLAM_ORB_MAX_LEVELS];
+    float scale[VSLAM_ORB_MAX_LEVELS];
+    const int32_t *level_count;                           // [level][frames]
+    int nl, nlevels_out, frames, cap;
+    vslam_orb_keypoint *out; float *out_angle; uint8_t *out_desc;
+    int32_t *count, *level_counts;                        // [frames], optional [frames][nlevels_out]
+};
+
+// One workgroup per frame: the levels' keypoint lists one after the other (level 0 first), positions scaled to the
+// base image as cv::ORB reports them (pt *= scale, in float).  A level that overflowed, or more keypoints than `cap`,
+// gives count -1 for the frame.
+__global__ __launch_bounds__(256) void orb_pack_kernel(OrbPackArgs a)
+{
+    __shared__ int off[VSLAM_ORB_MAX_LEVELS + 1];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int total = 0;
+        bool bad = false;
+        for (int l = 0; l < a.nl; ++l) {
+            const int k = a.level_count[(size_t)l * a.frames + f];
+            off[l] = total;
+            if (k < 0 || k > a.cap_l[l]) bad = true; else total += k;
+        }
+        off[a.nl] = total;
+        if (total > a.cap) bad = true;
+        a.count[f] = bad ? -1 : total;
+        if (a.level_counts)
+            for (int l = 0; l < a.nlevels_out; ++l) a.level_counts[(size_t)f * a.nlevels_out + l] = l < a.nl ? a.level_count[(size_t)l * a.frames + f] : 0;
+        if (bad) off[a.nl] = -1;
+    }
+    __syncthreads();
+    if (off[a.nl] < 0) return;
+    for (int l = 0; l < a.nl; ++l) {
+        const int k = off[l + 1] - off[l];
+        const vslam_feature *src = a.feat[l] + (size_t)f * a.cap_l[l];
+        vslam_orb_keypoint *dst = a.out + (size_t)f * a.cap + off[l];
+        for (int i = tid; i < k; i += 256) {
+            vslam_orb_keypoint kp;
+            kp.x = l == 0 ? (float)src[i].x : __fmul_rn((float)src[i].x, a.scale[l]);
+            kp.y = l == 0 ? (float)src[i].y : __fmul_rn((float)src[i].y, a.scale[l]);
+            kp.response = src[i].score; kp.octave = l;
+            dst[i] = kp;
+        }
+        if (a.out_desc) {
+            const float *sa = a.angle[l] + (size_t)f * a.cap_l[l];
+            float *da = a.out_angle + (size_t)f * a.cap + off[l];
+            for (int i = tid; i < k; i += 256) da[i] = sa[i];
+            const uint32_t *sd = reinterpret_cast<const uint32_t *>(a.desc[l] + (size_t)f * a.cap_l[l] * 32);
+            uint32_t *dd = reinterpret_cast<uint32_t *>(a.out_desc + ((size_t)f * a.cap + off[l]) * 32);
+            for (int i = tid; i < 8 * k; i += 256) dd[i] = sd[i];
+        }
+    }
+}
+
+extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride, size_t stride_frame,
+                                                               int frames, const vslam_orb_params *p, const int8_t *pattern,
+                                                               vslam_orb_keypoint *out, float *angle, uint8_t *desc, int cap, int32_t *count,
+                                                               int32_t *level_counts)
+{
+    if (!ctx) return VSLAM_ERR_ARG;
+    if (!gray || !p || !out || !count || cap < 1) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: null pointer or cap < 1");
+    if ((angle == nullptr) != (desc == nullptr)) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: angle and desc go together");
+    if (frames < 1 || frames > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect_and_compute_batch: frames=%d out of range", frames);
+    const bool describe = desc != nullptr;
+    if (describe && (reinterpret_cast<uintptr_t>(desc) & 3)) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: desc must be 4-byte aligned");
+    if (pattern && (reinterpret_cast<uintptr_t>(pattern) & 15)) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: the pattern must be 16-byte aligned");
+    int32_t lw[VSLAM_ORB_MAX_LEVELS], lh[VSLAM_ORB_MAX_LEVELS], lf[VSLAM_ORB_MAX_LEVELS];
+    float ls[VSLAM_ORB_MAX_LEVELS];
+    if (vslam_orb_level_plan(p, w, h, lw, lh, lf, ls) != VSLAM_OK) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: bad pyramid parameters");
+    if (stride < w || stride_frame < (size_t)stride * h) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect_and_compute_batch: stride %d < width %d or frames overlap", stride, w);
+    if (describe && p->edge_threshold < 23) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: edge_threshold %d < 23 (reach of the rotated pattern)", p->edge_threshold);
+    int nl = p->nlevels;
+    while (nl > 0 && (lw[nl - 1] < 2 * p->edge_threshold + 1 || lh[nl - 1] < 2 * p->edge_threshold + 1)) --nl;
+    for (int l = 0; l < nl; ++l) VSLAM_TRY(check_orb_level(ctx, lw[l], lh[l], lw[l], lf[l], p->fast_threshold, p->edge_threshold, p->harris_block));
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    VSLAM_TRY(ensure_lds_attr(ctx));
+    // per level room for the budget plus ties at the cut
+    OrbPackArgs pa;
+    size_t bytes = orb_ws_bytes(frames) + Arena::pad((size_t)VSLAM_ORB_MAX_LEVELS * frames * 4) + Arena::pad(VSLAM_ORB_PATTERN_BYTES);
+    for (int l = 0; l < nl; ++l) {
+        pa.cap_l[l] = std::min(SORT_S, lf[l] + 1024);
+        if (l > 0) bytes += Arena::pad((size_t)frames * lw[l] * lh[l]);
+        bytes += Arena::pad((size_t)frames * pa.cap_l[l] * sizeof(vslam_feature));
+        if (describe) bytes += Arena::pad((size_t)frames * pa.cap_l[l] * 4) + Arena::pad((size_t)frames * pa.cap_l[l] * 32);
+    }
+    if (describe) bytes += Arena::pad((size_t)frames * w * h);
+    VSLAM_TRY(ws_reserve(ctx, bytes));
+    Arena ar(ctx->ws);
+    void *dws = ar.take<char>(orb_ws_bytes(frames));
+    int32_t *dcount = ar.take<int32_t>((size_t)VSLAM_ORB_MAX_LEVELS * frames);
+    int8_t *dpattern = ar.take<int8_t>(VSLAM_ORB_PATTERN_BYTES);
+    uint8_t *dlev[VSLAM_ORB_MAX_LEVELS] = {nullptr};
+    vslam_feature *dfeat[VSLAM_ORB_MAX_LEVELS];
+    float *dangle[VSLAM_ORB_MAX_LEVELS] = {nullptr};
+    uint8_t *ddesc[VSLAM_ORB_MAX_LEVELS] = {nullptr};
+    for (int l = 0; l < nl; ++l) {
+        if (l > 0) dlev[l] = ar.take<uint8_t>((size_t)frames * lw[l] * lh[l]);
+        dfeat[l] = ar.take<vslam_feature>((size_t)frames * pa.cap_l[l]);
+        if (describe) { dangle[l] = ar.take<float>((size_t)frames * pa.cap_l[l]); ddesc[l] = ar.take<uint8_t>((size_t)frames * pa.cap_l[l] * 32); }
+    }
+    uint8_t *dblur = describe ? ar.take<uint8_t>((size_t)frames * w * h) : nullptr;
+    hipStream_t s = ctx->stream;
+    if (describe && !pattern) {
+        int8_t own[VSLAM_ORB_PATTERN_BYTES];
+        orb_default_pattern(own);
+        VSLAM_TRY(h2d(ctx, dpattern, own, VSLAM_ORB_PATTERN_BYTES));
+        pattern = dpattern;
+    }
+    for (int l = 0; l < nl; ++l) {
+        const uint8_t *img = gray;
+        int iw = w, ih = h, is = stride;
+        size_t ifr = stride_frame;
+        if (l > 0) {
+            const uint8_t *prev = l == 1 ? gray : dlev[l - 1];
+            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lw[l - 1];
+            const size_t pf = l == 1 ? stride_frame : (size_t)lw[l - 1] * lh[l - 1];
+            ifr = (size_t)lw[l] * lh[l];
+            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l], frames), dim3(256), 0, s, prev, pw, ph, ps, pf, dlev[l], lw[l],
+                               lh[l], lw[l], ifr);
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lw[l];
+        }
+        VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, ifr, frames, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
+                                   dfeat[l], pa.cap_l[l], dcount + (size_t)l * frames, dws));
+        if (describe) {
+            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, ifr, dblur, iw, (size_t)iw * ih, frames));
+            VSLAM_TRY(launch_orb_describe(ctx, img, is, ifr, dblur, iw, (size_t)iw * ih, iw, ih, frames, dfeat[l], dcount + (size_t)l * frames,
+                                          pa.cap_l[l], pattern, dangle[l], ddesc[l]));
+        }
+        pa.feat[l] = dfeat[l]; pa.angle[l] = dangle[l]; pa.desc[l] = ddesc[l]; pa.scale[l] = ls[l];
+    }
+    pa.level_count = dcount; pa.nl = nl; pa.nlevels_out = p->nlevels; pa.frames = frames; pa.cap = cap;
+    pa.out = out; pa.out_angle = angle; pa.out_desc = desc; pa.count = count; pa.level_counts = level_counts;
+    hipLaunchKernelGGL(orb_pack_kernel, dim3(frames), dim3(256), 0, s, pa);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
 }
 
 extern "C" vslam_status vslam_corner_response(vslam_ctx *ctx, const uint8_t *gray, int w, int h, int stride,

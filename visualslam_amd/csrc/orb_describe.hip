@@ -32,24 +32,40 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-__global__ __launch_bounds__(256) void gauss7_kernel(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+// 64 x 16 output pixels per workgroup: the 70 x 22 source pixels (reflected at the image sides) go to LDS once, the row
+// pass writes 22 x 64 sixteen-bit sums (at most 255 * 256) back to LDS, the column pass reads seven of them per output.
+constexpr int G7_W = 64, G7_H = 16;
+__global__ __launch_bounds__(256) void gauss7_kernel(const uint8_t *src, int w, int h, int sstride, size_t sframe, uint8_t *dst, int dstride,
+                                                     size_t dframe)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const unsigned wt[7] = {18u, 34u, 49u, 54u, 49u, 34u, 18u};
-    int xs[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) xs[i] = reflect101(x + i - 3, w);
-    unsigned acc = 0;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const uint8_t *row = src + (size_t)reflect101(y + j - 3, h) * sstride;
-        unsigned hsum = 0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) hsum += wt[i] * row[xs[i]];
-        acc += wt[j] * hsum;
+    __shared__ uint8_t px[(G7_H + 6) * (G7_W + 8)];
+    __shared__ uint16_t hs[(G7_H + 6) * G7_W];
+    const int tid = threadIdx.x, x0 = blockIdx.x * G7_W, y0 = blockIdx.y * G7_H;
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    for (int i = tid; i < (G7_H + 6) * (G7_W + 6); i += 256) {
+        const int r = i / (G7_W + 6), c = i - r * (G7_W + 6);
+        px[r * (G7_W + 8) + c] = src[(size_t)reflect101(min(y0 + r - 3, h + 2), h) * sstride + reflect101(min(x0 + c - 3, w + 2), w)];
     }
-    dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+    __syncthreads();
+    const unsigned wt[7] = {18u, 34u, 49u, 54u, 49u, 34u, 18u};
+    for (int i = tid; i < (G7_H + 6) * G7_W; i += 256) {
+        const int r = i / G7_W, c = i - r * G7_W;
+        const uint8_t *p = px + r * (G7_W + 8) + c;
+        unsigned sum = 0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) sum += wt[t] * p[t];
+        hs[i] = (uint16_t)sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < G7_H * G7_W; i += 256) {
+        const int r = i / G7_W, c = i - r * G7_W, x = x0 + c, y = y0 + r;
+        if (x >= w || y >= h) continue;
+        unsigned acc = 0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc += wt[t] * hs[(r + t) * G7_W + c];
+        dst[(size_t)y * dstride + x] = (uint8_t)((acc + 32768u) >> 16);
+    }
 }
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -73,6 +89,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 struct DescArgs {
     const uint8_t *gray, *blur;
+    size_t gframe, bframe;                    // frame f of a batch: gray + f * gframe, blur + f * bframe
     int w, h, stride, bstride;
     const vslam_feature *kp;
     const int32_t *count;
@@ -85,9 +102,11 @@ struct DescArgs {
 
 __global__ __launch_bounds__(256) void orb_describe_kernel(DescArgs a)
 {
-    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = min(*a.count, a.max_count);
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
+    const int n = min(a.count[f], a.max_count);
     if (i >= n) return;
+    a.kp += (size_t)f * a.max_count; a.angle += (size_t)f * a.max_count; a.desc += (size_t)f * a.max_count * 32;
+    a.gray += (size_t)f * a.gframe; a.blur += (size_t)f * a.bframe;
     const int x = a.kp[i].x, y = a.kp[i].y;
     if (x < kReach || y < kReach || x >= a.w - kReach || y >= a.h - kReach) {      // patch would leave the image: no orientation, zero descriptor
         if (lane == 0) a.angle[i] = -1.0f;
@@ -148,23 +167,25 @@ void patch_half_widths(unsigned long long *lo, unsigned long long *hi)
 
 }  // namespace
 
-vslam_status launch_gauss7(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+vslam_status launch_gauss7(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, size_t sframe, uint8_t *dst, int dstride,
+                           size_t dframe, int frames)
 {
-    hipLaunchKernelGGL(gauss7_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, src, w, h, sstride, dst, dstride);
+    hipLaunchKernelGGL(gauss7_kernel, dim3((w + G7_W - 1) / G7_W, (h + G7_H - 1) / G7_H, frames), dim3(256), 0, ctx->stream, src, w, h, sstride,
+                       sframe, dst, dstride, dframe);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
 
-vslam_status launch_orb_describe(vslam_ctx *ctx, const uint8_t *gray, int stride, const uint8_t *blur, int bstride, int w, int h,
-                                 const vslam_feature *kp, const int32_t *count, int max_count, const int8_t *pattern,
-                                 float *angle, uint8_t *desc)
+vslam_status launch_orb_describe(vslam_ctx *ctx, const uint8_t *gray, int stride, size_t gframe, const uint8_t *blur, int bstride,
+                                 size_t bframe, int w, int h, int frames, const vslam_feature *kp, const int32_t *count, int max_count,
+                                 const int8_t *pattern, float *angle, uint8_t *desc)
 {
-    if (max_count < 1) return VSLAM_OK;
+    if (max_count < 1 || frames < 1) return VSLAM_OK;
     DescArgs a;
-    a.gray = gray; a.blur = blur; a.w = w; a.h = h; a.stride = stride; a.bstride = bstride;
+    a.gray = gray; a.blur = blur; a.gframe = gframe; a.bframe = bframe; a.w = w; a.h = h; a.stride = stride; a.bstride = bstride;
     a.kp = kp; a.count = count; a.max_count = max_count; a.pattern = pattern; a.angle = angle; a.desc = desc;
     patch_half_widths(&a.umax_lo, &a.umax_hi);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_count + 3) / 4), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((max_count + 3) / 4, frames), dim3(256), 0, ctx->stream, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -206,7 +227,7 @@ extern "C" vslam_status vslam_gaussian_blur7_dev(vslam_ctx *ctx, const uint8_t *
     if (w < 1 || h < 1 || sstride < w || dstride < w || w > 65535 || h > 65535)
         return fail(ctx, VSLAM_ERR_SHAPE, "gaussian_blur7: %dx%d (strides %d, %d)", w, h, sstride, dstride);
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_gauss7(ctx, src, w, h, sstride, dst, dstride);
+    return launch_gauss7(ctx, src, w, h, sstride, 0, dst, dstride, 0, 1);
 }
 
 extern "C" vslam_status vslam_orb_describe_level_dev(vslam_ctx *ctx, const uint8_t *gray, int stride, const uint8_t *blurred, int bstride,
@@ -218,5 +239,5 @@ extern "C" vslam_status vslam_orb_describe_level_dev(vslam_ctx *ctx, const uint8
     if (w < 1 || h < 1 || stride < w || bstride < w || max_count < 0) return fail(ctx, VSLAM_ERR_SHAPE, "orb_describe: %dx%d (strides %d, %d), %d keypoints", w, h, stride, bstride, max_count);
     if (reinterpret_cast<uintptr_t>(pattern) & 15) return fail(ctx, VSLAM_ERR_ARG, "orb_describe: the pattern must be 16-byte aligned");
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_orb_describe(ctx, gray, stride, blurred, bstride, w, h, keypoints, count, max_count, pattern, angle, desc);
+    return launch_orb_describe(ctx, gray, stride, 0, blurred, bstride, 0, w, h, 1, keypoints, count, max_count, pattern, angle, desc);
 }
