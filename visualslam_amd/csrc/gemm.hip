@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     constexpr int LDA_S = BM + 16, LDB_S = BN + 16;       // (stride mod 32 doubles) == 16
     constexpr int TMw = BM / 32, TNw = BN / 32;           // 16x16 MFMA tiles per wave and dimension
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256; // staged elements per thread
-    __shared__ double As[BK * LDA_S];
-    __shared__ double Bs[BK * LDB_S];
+    __shared__ double As2[2][BK * LDA_S];                   // two K-steps resident: one barrier per step
+    __shared__ double Bs2[2][BK * LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_m = blockIdx.x % g.tilesM, tile_n = blockIdx.x / g.tilesM;
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
             rb[e] = (k0 + k < k_end) ? fetch_b<TB>(g, B, k0 + k, n0 + n) : 0.0;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        double *As = As2[buf], *Bs = Bs2[buf];
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
             const int idx = tid + e * 256;
@@ -114,10 +115,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
 
     if (k_begin < k_end) {
         load_tiles(k_begin);
-        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-            store_tiles();
-            __syncthreads();
-            if (k0 + BK < k_end) load_tiles(k0 + BK);     // in flight during the MFMAs below
+        store_tiles(0);
+        __syncthreads();
+        if (k_begin + BK < k_end) load_tiles(k_begin + BK);   // in flight during the MFMAs below
+        int buf = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK, buf ^= 1) {
+            const double *As = As2[buf], *Bs = Bs2[buf];
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 4) {
                 const int krow = kk + (lane >> 4);
@@ -132,7 +135,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
                     for (int j = 0; j < TNw; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
             }
+            if (k0 + BK < k_end) store_tiles(buf ^ 1);        // nobody reads that buffer during this step
             __syncthreads();
+            if (k0 + 2 * BK < k_end) load_tiles(k0 + 2 * BK);
         }
     }
     // acc[i][j][r] = C[m0+wm+16i+(lane&15)][n0+wn+16j+(lane>>4)+4r]
