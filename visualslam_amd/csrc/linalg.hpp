@@ -118,7 +118,8 @@ inline bool trs_multiplier_settled(double ff, double Delta) { return std::fabs(f
 
 size_t newton_ws_bytes(int n);
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
-vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active);
+vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
+                                   bool zero_lower = true);
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
                                 int *status_out);

@@ -141,8 +141,10 @@ __global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA
 // In-place upper Cholesky A = U^T U of `batch` symmetric n x n matrices (element stride strideA; both
 // triangles are overwritten: U above, zeros below).  info: one device word per matrix, 0 on entry.
 // active (device, may be null): matrices whose entry is 0 are left alone (except for the zeroing of
-// their strict lower triangle).
-vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active)
+// their strict lower triangle).  zero_lower = false leaves the strict lower triangle as it is (a caller
+// that only ever reads the upper triangle of the factor saves the pass).
+vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
+                                   bool zero_lower)
 {
     hipStream_t s = ctx->stream;
     for (int j0 = 0; j0 < n; j0 += CB) {
@@ -160,6 +162,7 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
         g.batch = batch; g.active = active;
         VSLAM_TRY(gemm_f64(ctx, g));
     }
+    if (!zero_lower) return VSLAM_OK;
     const size_t zblocks = ((size_t)n * n + 4095) / 4096;
     hipLaunchKernelGGL(zero_below_diag_kernel, dim3((unsigned)(zblocks < 1024 ? zblocks : 1024), batch), dim3(256), 0, s, A, lda, n, strideA, active);
     VSLAM_HIP_TRY(ctx, hipGetLastError());

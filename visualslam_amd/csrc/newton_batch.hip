@@ -158,15 +158,18 @@ __global__ void bk_copy_kernel(double *dst, const double *src, size_t count, con
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[base + i] = src[base + i];
 }
 
-// U[b] = H[b] + lam[b] I  (n x n, ld n), active instances only
+// upper triangle of U[b] = that of H[b] + lam[b] I  (n x n, ld n), active instances only; the factorisation and the
+// solves that follow never touch the strict lower triangle.  One column per blockIdx.x step.
 __global__ void bk_shifted_copy_kernel(double *U, const double *H, int n, const double *lam, const int *active)
 {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
-    const size_t nn = (size_t)n * n, base = (size_t)b * nn, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t base = (size_t)b * n * n;
     const double l = lam[b];
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nn; idx += stride)
-        U[base + idx] = H[base + idx] + ((idx % (size_t)(n + 1) == 0) ? l : 0.0);
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        const size_t col = base + (size_t)c * n;
+        for (int r = threadIdx.x; r <= c; r += blockDim.x) U[col + r] = H[col + r] + (r == c ? l : 0.0);
+    }
 }
 
 // out[b] = a[b] - c[b] / out[b] = -(a[b] + c[b]) over `count` doubles per instance, active instances only
@@ -289,9 +292,9 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     // for the instances of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&]() -> vslam_status {
         VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)B * 8));
-        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
+        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), B), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active));
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false));
         trsv(w.U, true, w.gcur, w.t, 1.0, w.active);
         trsv(w.U, false, w.t, w.p, -1.0, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
