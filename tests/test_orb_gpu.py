@@ -310,3 +310,48 @@ def test_batch_reports_a_frame_that_does_not_fit(ctx):
     api.orb_detect_and_compute_batch_dev(ctx, frames, out, cnt, params)
     ctx.synchronize()
     assert cnt.cpu().numpy().tolist() == [-1, 0]                              # too many for cap; a flat frame has none
+
+
+@pytest.mark.parametrize("shape,nlevels,nfeat", [((200, 260), 8, 300), ((151, 151), 1, 50), ((480, 640), 3, 0), ((150, 400), 4, 100)])
+def test_small_images_and_few_levels(ctx, shape, nlevels, nfeat):
+    """Images barely larger than twice the edge threshold (levels that fall below it are skipped), a single level, a
+    zero feature budget, an image too small for any level: the host entry against the oracle, level by level."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    img = np.random.default_rng(shape[0] + nlevels).integers(0, 256, shape, dtype=np.uint8)
+    params = api.orb_params(nfeatures=nfeat, nlevels=nlevels)
+    kp, ang, dsc, lev = api.orb_detect_and_compute(ctx, img, params)
+    okp, oang, odesc, _ = orc.orb_detect_and_compute(img, nfeatures=nfeat, nlevels=nlevels)
+    assert [int(v) for v in lev] == [k.size for k in okp]
+    pos = 0
+    for l, (k, a, d) in enumerate(zip(okp, oang, odesc)):
+        sl = slice(pos, pos + k.size)
+        assert (kp["octave"][sl] == l).all() and np.array_equal(kp["response"][sl].view(np.uint32), k["score"].view(np.uint32))
+        assert np.array_equal(ang[sl].view(np.uint32), a.view(np.uint32)) and np.array_equal(dsc[sl], d)
+        pos += k.size
+    assert pos == kp.size
+    if shape == (150, 400) or nfeat == 0:
+        assert kp.size == 0                                   # 150 rows < 2 * 75 + 1: nothing lies inside the edge
+
+
+def test_batch_with_a_callers_pattern(ctx):
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    img = syn.frame(40)[:600, :800].copy()
+    pattern = np.random.default_rng(2).integers(-15, 16, 1024).astype(np.int8)
+    params = api.orb_params(nfeatures=400, nlevels=2)
+    dev = torch.device("cuda:0")
+    frames = torch.tensor(img[None], device=dev)
+    cap = 2048
+    out = torch.zeros((1, cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    angle = torch.zeros((1, cap), dtype=torch.float32, device=dev)
+    desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+    api.orb_detect_and_compute_batch_dev(ctx, frames, out, cnt, params, pattern=torch.tensor(pattern, device=dev), angle=angle, desc=desc)
+    ctx.synchronize()
+    okp, oang, odesc, _ = orc.orb_detect_and_compute(img, nfeatures=400, nlevels=2, pattern=pattern)
+    k = int(cnt[0])
+    assert k == sum(x.size for x in okp) > 100
+    assert np.array_equal(desc[0, :k].cpu().numpy(), np.concatenate(odesc))
+    assert np.array_equal(angle[0, :k].cpu().numpy().view(np.uint32), np.concatenate(oang).view(np.uint32))

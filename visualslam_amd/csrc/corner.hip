@@ -1381,7 +1381,8 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
     int32_t lw[VSLAM_ORB_MAX_LEVELS], lh[VSLAM_ORB_MAX_LEVELS], lf[VSLAM_ORB_MAX_LEVELS];
     float ls[VSLAM_ORB_MAX_LEVELS];
     if (vslam_orb_level_plan(p, w, h, lw, lh, lf, ls) != VSLAM_OK) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: bad pyramid parameters");
-    if (stride < w || stride_frame < (size_t)stride * h) return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect_and_compute_batch: stride %d < width %d or frames overlap", stride, w);
+    if (stride < w || (frames > 1 && stride_frame < (size_t)stride * (h - 1) + w))
+        return fail(ctx, VSLAM_ERR_SHAPE, "orb_detect_and_compute_batch: stride %d < width %d or frames overlap (frame stride %zu)", stride, w, stride_frame);
     if (describe && p->edge_threshold < 23) return fail(ctx, VSLAM_ERR_ARG, "orb_detect_and_compute_batch: edge_threshold %d < 23 (reach of the rotated pattern)", p->edge_threshold);
     int nl = p->nlevels;
     while (nl > 0 && (lw[nl - 1] < 2 * p->edge_threshold + 1 || lh[nl - 1] < 2 * p->edge_threshold + 1)) --nl;
