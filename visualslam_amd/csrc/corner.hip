@@ -343,7 +343,14 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
 {
     __shared__ uint64_t stage[2][128];
     const int lane = threadIdx.x;
-    int bid = blockIdx.x;
+    // Workgroup ids are dealt round-robin to the eight XCDs, each with an L2 of its own.  Renumbered so that an XCD
+    // works through one contiguous run of (frame, band, strip): neighbouring strips and bands, which share their halo
+    // columns and rows, then meet in the same L2 instead of fetching them from HBM once per XCD.
+    int bid;
+    {
+        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+        bid = x * q + min(x, r) + ((int)blockIdx.x >> 3);
+    }
     const int strip = bid % nstrips; bid /= nstrips;
     const int seg = bid % nseg, frame = bid / nseg;
     const int w = a.w, h = a.h;
