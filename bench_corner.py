@@ -100,10 +100,16 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
     fast_ms = f0.elapsed_time(f1) / freps
     fk = float(fcnt.clamp(min=0).sum().item()) / F
     falg = (W * H + 12.0 * fk) * F
+    ftraffic = None
+    ffile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_fast9.json")
+    if F == 64 and os.path.exists(ffile):
+        with open(ffile) as fh:
+            ftraffic = json.load(fh).get("hbm_bytes_per_step")
     res["fast9"] = {"value": F / (fast_ms * 1e-3), "unit": "frames/s", "ms_per_step": fast_ms, "threshold": 20, "nonmax": True,
                     "mean_keypoints_per_frame": fk, "overflowed_frames": int((fcnt < 0).sum().item()),
                     "roofline": {"bound": "hbm", "kernel": "fast9_tile_kernel + sort/merge/emit", "achieved": falg / (fast_ms * 1e-3) / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": falg / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": falg / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ftraffic,
+                                 "traffic_source": "replayed from profiles/traffic_fast9.json (rocprofv3 --pmc passes of tools/run_fast9.py 64); not re-measured in this run",
                                  "algorithmic_bytes_per_step": falg}}
     # ORB as the reference configures it: level-0 keypoints (FAST -> edge -> 2n by FAST score -> Harris at the corners
     # -> n best) for all frames in one call, then blur + orientation + descriptors frame by frame; and the whole

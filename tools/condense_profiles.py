@@ -117,6 +117,24 @@ def main():
                        "algorithmic_bytes_per_step": 64 * 1920 * 1080 + 12 * 64 * (1873 + 6265)}, f, indent=1)
         print("corner HBM bytes per step %.0f" % ctotal)
 
+    ff_db, fw_db = os.path.join(SRC, "fast_fetch", "fetch_results.db"), os.path.join(SRC, "fast_write", "write_results.db")
+    if os.path.exists(ff_db) and os.path.exists(fw_db):
+        names = ["fast9_tile_kernel", "sort_chunk_kernel", "merge_chunks_kernel", "emit_features_kernel"]
+        ff, fw = counters(ff_db, names), counters(fw_db, names)
+        fk, ftotal = {}, 0.0
+        for k in ff:
+            fkb, wkb = ff[k]["FETCH_SIZE"], fw.get(k, {}).get("WRITE_SIZE", 0.0)
+            per_step = ff[k]["launches"] / 3.0          # run_fast9.py 64 3 = three steps
+            fk[k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb, "launches_per_step": per_step,
+                     "bytes_per_step": (2 * fkb + wkb) * 1024 * per_step}
+            ftotal += fk[k]["bytes_per_step"]
+        with open(os.path.join(DST, "traffic_fast9.json"), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/run_fast9.py 64 3",
+                       "workload": "64 frames 1920x1080, FAST-9/16 threshold 20 with non-maximum suppression, keypoints out",
+                       "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE taken as is; units KB",
+                       "kernels": fk, "hbm_bytes_per_step": ftotal}, f, indent=1)
+        print("fast9 HBM bytes per step %.0f" % ftotal)
+
     sq = counters(os.path.join(SRC, "corner_sq", "sq_results.db"), ["corner_strip_kernel", "corner_tile_kernel"])
     with open(os.path.join(DST, tag + "_corner_sq_counters.json"), "w") as f:
         json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU "

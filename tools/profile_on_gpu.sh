@@ -13,6 +13,8 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o write -- pytho
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d "$OUT/corner_sq" -o sq -- python3 "$R/tools/run_corner.py" 64 3 > "$OUT/corner_sq.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/corner_fetch" -o fetch -- python3 "$R/tools/run_corner.py" 64 3 > "$OUT/corner_fetch.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/corner_write" -o write -- python3 "$R/tools/run_corner.py" 64 3 > "$OUT/corner_write.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fast_fetch" -o fetch -- python3 "$R/tools/run_fast9.py" 64 3 > "$OUT/fast_fetch.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$OUT/fast_write" -o write -- python3 "$R/tools/run_fast9.py" 64 3 > "$OUT/fast_write.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/qr" -o qr -- python3 "$R/tools/qr_bench.py" 6012 6012 2 > "$OUT/qr.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA -d "$OUT/qr_mfma" -o mfma -- python3 "$R/tools/qr_bench.py" 6012 6012 1 > "$OUT/qr_mfma.log" 2>&1 || echo "mfma counter pass failed (counter names may differ)" > "$OUT/qr_mfma.failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_affine" -o bank_affine -- python3 "$R/tools/run_bank_affine.py" 512 150 3 > "$OUT/bank_affine.log" 2>&1 || exit 1
