@@ -65,7 +65,19 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     __shared__ double Bs2[2][BK * LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_m = blockIdx.x % g.tilesM, tile_n = blockIdx.x / g.tilesM;
+    // Tile order.  Workgroup ids are dealt round-robin to the eight XCDs (an L2 each): renumbered so that an XCD works
+    // through one contiguous run of tiles, and the tiles ordered in groups of eight tile rows swept along N, so that
+    // the tiles an XCD has in flight share a few row blocks of A and column blocks of B that stay in its L2.
+    // (Not for the triangular updates: their empty tiles below the diagonal would gather on a few XCDs.)
+    int tile_m = blockIdx.x % g.tilesM, tile_n = blockIdx.x / g.tilesM;
+    if (!g.c_upper) {
+        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+        const int l = x * q + min(x, r) + ((int)blockIdx.x >> 3);
+        const int tilesN = nb / g.tilesM, per_group = 8 * tilesN, group = l / per_group, first_m = group * 8;
+        const int gsz = min(8, g.tilesM - first_m), in_group = l - group * per_group;
+        tile_m = first_m + in_group % gsz;
+        tile_n = in_group / gsz;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (g.c_upper && m0 > n0 + BN - 1) return;             // tile entirely below the diagonal of C: not wanted
     const int split = blockIdx.y, b = blockIdx.z;
