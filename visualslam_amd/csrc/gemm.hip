@@ -94,6 +94,22 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TNw; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
+    // C = alpha A B + beta C: the old values of this tile are requested before the products are formed, so that the
+    // update at the end does not wait for them (a tile of a rank-64 update has only four K-steps to hide a load behind)
+    const bool rmw = gridDim.y == 1 && g.beta != 0.0;
+    double cold[TMw][TNw][4];
+    if (rmw) {
+#pragma unroll
+        for (int i = 0; i < TMw; ++i)
+#pragma unroll
+            for (int j = 0; j < TNw; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = min(m0 + wm + 16 * i + (lane & 15), g.M - 1), n = min(n0 + wn + 16 * j + (lane >> 4) + 4 * r, g.N - 1);
+                    cold[i][j][r] = C[(size_t)n * g.ldc + m];
+                }
+    }
+
     double ra[EA], rb[EB];
     auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
                 if (m < g.M && n < g.N) {
                     double *p = C + (size_t)n * g.ldc + m;
                     if (split_mode) *p = acc[i][j][r];
-                    else *p = (g.beta == 0.0) ? g.alpha * acc[i][j][r] : g.alpha * acc[i][j][r] + g.beta * (*p);
+                    else *p = rmw ? g.alpha * acc[i][j][r] + g.beta * cold[i][j][r] : g.alpha * acc[i][j][r];
                 }
             }
 }
