@@ -106,7 +106,8 @@ def test_bank_with_collapsed_trust_region_matches_eigenvalue_route(ctx, gcam):
     """Filters whose last iterations are rejected steps with a shrinking radius (the cost no longer resolves the
     step, rho is rounding noise): there the bank's multiplier iteration stops on |ff| * Delta < 1e-10, before the
     reference's |ff| < sqrt(eps).  The posterior must still agree with the eigenvalue route of the single-filter
-    entry to 1e-9; iteration counts may differ by the accept/reject decisions taken on rounding noise."""
+    entry: to 1e-9 where the iteration counts agree; the counts may differ by accept/reject decisions taken on
+    rounding noise, and the results are then compared against the posterior spread."""
     import torch
     from visualslam_amd import api
     from visualslam_amd import synthetic as syn
@@ -135,8 +136,14 @@ def test_bank_with_collapsed_trust_region_matches_eigenvalue_route(ctx, gcam):
             S1 = Sp[b].cpu().numpy().T
             assert code[b] == c0
             assert abs(int(iters[b]) - it0) <= 4
-            assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
-            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+            if int(iters[b]) == it0:
+                assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+                assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+            else:
+                # one route accepted a step of rounding-noise size that the other rejected: the means differ by
+                # such a step, tiny against the posterior spread
+                assert np.linalg.norm(np.linalg.solve(S0.T, m1 - m0)) <= 1e-6
+                assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-6
     finally:
         ctx.set_trs_solver(api.TRS_CHOLESKY)
 

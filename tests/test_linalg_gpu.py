@@ -250,3 +250,40 @@ def test_qr_batched_dev(ctx):
         R0 = np.linalg.qr(A[b].T, mode="r")
         assert rel_err(out[b].T[:k], R0) <= 1e-11
     tctx.close()
+
+
+def _trtri(ctx, S):
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    S = np.ascontiguousarray(S, dtype=np.float64)          # [batch][col][row]: each matrix column-major
+    batch, n = (1, S.shape[0]) if S.ndim == 2 else (S.shape[0], S.shape[1])
+    W = np.full_like(S, np.nan)
+    fn = L.vslam_debug_trtri
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert fn(ctx.ptr, S.ctypes.data, n, batch, W.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
+    return W
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 130, 200, 462, 1000, 2100])
+def test_triangular_inverse(ctx, n):
+    """Every size class of the bottom-up inverse: one block, a ragged second block, full and ragged pairs on several
+    levels; rectangular triangular-times-dense products with the zero stretch of K skipped."""
+    rng = np.random.default_rng(n)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + np.diag(1.0 + rng.random(n))
+    U_low_garbage = U + np.tril(rng.standard_normal((n, n)), -1)       # the strict lower triangle must not be read
+    W = _trtri(ctx, np.ascontiguousarray(U_low_garbage.T)).T           # column-major on the device
+    assert not np.tril(W, -1).any()
+    assert rel_err(W @ U, np.eye(n)) <= 1e-12
+    assert rel_err(W, np.linalg.inv(U)) <= 1e-11
+
+
+def test_triangular_inverse_bank(ctx):
+    rng = np.random.default_rng(11)
+    B, n = 5, 333
+    U = np.triu(rng.standard_normal((B, n, n))) / np.sqrt(n) + np.eye(n) * (1.0 + rng.random((B, n, 1)))
+    W = _trtri(ctx, np.ascontiguousarray(np.transpose(U, (0, 2, 1))))
+    W = np.transpose(W, (0, 2, 1))
+    for b in range(B):
+        assert rel_err(W[b], np.linalg.inv(U[b])) <= 1e-11
+        assert not np.tril(W[b], -1).any()

@@ -85,7 +85,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     const double *A = g.A + (size_t)b * g.sA;
     const double *B = g.B + (size_t)b * g.sB;
     double *C = g.C + (size_t)b * g.sC + (size_t)split * g.sSplit;
-    const int k_begin = split * g.kchunk, k_end = min(g.K, k_begin + g.kchunk);
+    int k_begin = split * g.kchunk, k_end = min(g.K, k_begin + g.kchunk);
+    // Triangular operands: the stretch of K over which an operand of this tile is identically zero is skipped
+    // (products of triangular factors and inverses then cost the flops of their non-zero parts only).
+    if (g.amode == A_UPPER) {
+        if (TA) k_end = min(k_end, m0 + BM);                 // stored (k, m): zero for k > m
+        else k_begin = max(k_begin, m0);                     // stored (m, k): zero for k < m
+    }
+    if (g.b_upper) {
+        if (TB) k_begin = max(k_begin, n0);                  // stored (n, k): zero for k < n
+        else k_end = min(k_end, n0 + BN);                    // stored (k, n): zero for k > n
+    }
 
     const int wm = (wave & 1) * (BM / 2), wn = (wave >> 1) * (BN / 2);
     double4_t acc[TMw][TNw];

@@ -9,24 +9,26 @@
 // the O(n^2) vector solves run as blocked substitution, one launch per diagonal block.
 #include "linalg.hpp"
 
+#include <algorithm>
+
 namespace vslam {
 
 constexpr int TBK = 64;          // diagonal block of the triangular inverse
 
 // Workgroup b (one wave) inverts the upper-triangular diagonal block b (64 x 64, the last one
-// smaller) of S; D[b] (ld TBK, zeros below the diagonal) receives the inverse.  Lane c owns column
+// smaller) of S into the same block of W (zeros below the diagonal).  Lane c owns column
 // c of the inverse and back-substitutes e_c:  x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r];
 // both matrices live in LDS (U read as broadcasts, the inverse lane-contiguous).
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *Dall, size_t strideS, size_t strideD)
+__global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *W, int ldW, size_t strideS, size_t strideW)
 {
     S += (size_t)blockIdx.y * strideS;                 // instance blockIdx.y of a batch
-    Dall += (size_t)blockIdx.y * strideD;
+    W += (size_t)blockIdx.y * strideW;
     extern __shared__ double trtri_lds[];
     double *U = trtri_lds;                        // [TBK][TBK + 1]
     double *X = trtri_lds + TBK * (TBK + 1);      // [TBK][TBK], X[r][c]
     const int c = threadIdx.x, j0 = blockIdx.x * TBK, jb = min(TBK, n - j0);
     const double *Sb = S + (size_t)j0 * ldS + j0;
-    double *D = Dall + (size_t)blockIdx.x * TBK * TBK;
+    double *D = W + (size_t)j0 * ldW + j0;
     for (int cb = 0; cb < TBK; cb += 16) {        // lane = row: coalesced column reads, 16 in flight
         double v[16];
 #pragma unroll
@@ -43,15 +45,9 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS
         X[r * TBK + c] = (r <= c) ? num / U[r * (TBK + 1) + r] : 0.0;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < TBK; ++r) D[(size_t)c * TBK + r] = (c < jb && r <= c) ? X[r * TBK + c] : 0.0;
-}
-
-__global__ void copy_block_kernel(const double *src, int lds, double *dst, int ldd, int rows, int cols, double scale, size_t stride_src,
-                                  size_t stride_dst)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (r < rows && c < cols) dst[(size_t)blockIdx.z * stride_dst + (size_t)c * ldd + r] = scale * src[(size_t)blockIdx.z * stride_src + (size_t)c * lds + r];
+    // lane = row of the inverse: a column of W is written as one contiguous run
+    for (int cc = 0; cc < jb; ++cc)
+        if (c < jb) D[(size_t)cc * ldW + c] = X[c * TBK + cc];
 }
 
 __global__ void zero_lower_block_kernel(double *W, int ldW, int n, size_t strideW)
@@ -60,42 +56,64 @@ __global__ void zero_lower_block_kernel(double *W, int ldW, int n, size_t stride
     if (r < n && r > c) W[(size_t)blockIdx.z * strideW + (size_t)c * ldW + r] = 0.0;
 }
 
-size_t trtri_ws_bytes(int n) { return Arena::pad((size_t)((n + TBK - 1) / TBK) * TBK * TBK * 8) + Arena::pad((size_t)n * TBK * 8); }
-size_t trtri_batch_ws_bytes(int n, int batch)
+// Scratch of the triangular inverse: the products S12 W22 of one level (see below).
+static size_t trtri_tmp_doubles(int n, int batch)
 {
-    return Arena::pad((size_t)batch * ((n + TBK - 1) / TBK) * TBK * TBK * 8) + Arena::pad((size_t)batch * n * TBK * 8);
+    size_t need = 1;
+    for (int b = TBK; b < n; b *= 2) {
+        const int full = n / (2 * b), i0 = full * 2 * b;
+        const int r = (i0 + b < n) ? n - i0 - b : 0;                     // the ragged pair behind the full ones
+        const size_t lvl = batch == 1 ? std::max((size_t)full * b * b, (size_t)b * r) : (size_t)batch * b * (full > 0 ? b : r);
+        need = std::max(need, lvl);
+    }
+    return need;
 }
+size_t trtri_ws_bytes(int n) { return Arena::pad(trtri_tmp_doubles(n, 1) * 8); }
+size_t trtri_batch_ws_bytes(int n, int batch) { return Arena::pad(trtri_tmp_doubles(n, batch) * 8); }
 
-// W = S^-1 for `batch` upper-triangular matrices (element strides strideS / strideW).
+// W = S^-1 for `batch` upper-triangular matrices (element strides strideS / strideW), bottom up: every 64 x 64
+// diagonal block is inverted by one launch, then neighbouring blocks of width b = 64, 128, 256, ... are joined,
+//     [S11 S12; 0 S22]^-1 = [W11  -W11 S12 W22; 0  W22],
+// all pairs of a level in two GEMM launches (one matrix: the pairs are the batch dimension of the GEMM; a bank of
+// matrices: one pair at a time with the matrices as the batch dimension).  The products are large and few instead
+// of a thin one per block column: 2 log2(n / 64) launches on the matrix cores.
 vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
                                    int batch, void *ws)
 {
     Arena ar(ws);
     const int nblk = (n + TBK - 1) / TBK;
-    const size_t strideD = (size_t)nblk * TBK * TBK, strideT = (size_t)n * TBK;
-    double *Dall = ar.take<double>((size_t)batch * strideD);
-    double *Tmp = ar.take<double>((size_t)batch * strideT);
+    double *Tmp = ar.take<double>(trtri_tmp_doubles(n, batch));
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, s, W, ldW, n, strideW);
     const size_t dlds = (size_t)(TBK * (TBK + 1) + TBK * TBK) * 8;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), dlds, s, S, ldS, n, Dall, strideS, strideD);
-    for (int j0 = 0; j0 < n; j0 += TBK) {
-        const int jb = (n - j0) < TBK ? (n - j0) : TBK;
-        const double *D = Dall + (size_t)(j0 / TBK) * TBK * TBK;
-        hipLaunchKernelGGL(copy_block_kernel, dim3(1, jb, batch), dim3(64), 0, s, D, TBK, W + (size_t)j0 * ldW + j0, ldW, jb, jb, 1.0, strideD, strideW);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
-        if (j0 == 0) continue;
-        GemmDesc g1;                       // Tmp = W[0:j0,0:j0] * S[0:j0, J]
-        g1.M = j0; g1.N = jb; g1.K = j0; g1.transA = false; g1.transB = false; g1.amode = A_UPPER;
-        g1.A = W; g1.lda = ldW; g1.strideA = strideW; g1.B = S + (size_t)j0 * ldS; g1.ldb = ldS; g1.strideB = strideS;
-        g1.C = Tmp; g1.ldc = n; g1.strideC = strideT; g1.batch = batch;
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), dlds, s, S, ldS, n, W, ldW, strideS, strideW);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    // pairs [i0, i0+b) and [i0+b, i0+b+r) of one level: `count` of them `pair_stride` blocks apart (or the bank)
+    auto join = [&](int i0, int b, int r, int count) -> vslam_status {
+        const bool bank = batch > 1;
+        const size_t ps = (size_t)2 * b;
+        GemmDesc g1;                       // Tmp = S12 W22
+        g1.M = b; g1.N = r; g1.K = r; g1.transA = false; g1.transB = false; g1.b_upper = true;
+        g1.A = S + (size_t)(i0 + b) * ldS + i0; g1.lda = ldS; g1.strideA = bank ? strideS : ps * ldS + ps;
+        g1.B = W + (size_t)(i0 + b) * ldW + i0 + b; g1.ldb = ldW; g1.strideB = bank ? strideW : ps * ldW + ps;
+        g1.C = Tmp; g1.ldc = b; g1.strideC = (size_t)b * r; g1.batch = bank ? batch : count;
         VSLAM_TRY(gemm_f64(ctx, g1));
-        GemmDesc g2;                       // W[0:j0, J] = -Tmp * D
-        g2.M = j0; g2.N = jb; g2.K = jb; g2.transA = false; g2.transB = false; g2.b_upper = true; g2.alpha = -1.0;
-        g2.A = Tmp; g2.lda = n; g2.strideA = strideT; g2.B = D; g2.ldb = TBK; g2.strideB = strideD;
-        g2.C = W + (size_t)j0 * ldW; g2.ldc = ldW; g2.strideC = strideW; g2.batch = batch;
-        VSLAM_TRY(gemm_f64(ctx, g2));
+        GemmDesc g2;                       // W12 = -W11 Tmp
+        g2.M = b; g2.N = r; g2.K = b; g2.transA = false; g2.transB = false; g2.amode = A_UPPER; g2.alpha = -1.0;
+        g2.A = W + (size_t)i0 * ldW + i0; g2.lda = ldW; g2.strideA = bank ? strideW : ps * ldW + ps;
+        g2.B = Tmp; g2.ldb = b; g2.strideB = (size_t)b * r;
+        g2.C = W + (size_t)(i0 + b) * ldW + i0; g2.ldc = ldW; g2.strideC = bank ? strideW : ps * ldW + ps; g2.batch = bank ? batch : count;
+        return gemm_f64(ctx, g2);
+    };
+    for (int b = TBK; b < n; b *= 2) {
+        const int full = n / (2 * b), i0r = full * 2 * b;
+        if (batch == 1) {
+            if (full > 0) VSLAM_TRY(join(0, b, b, full));
+        } else {
+            for (int p = 0; p < full; ++p) VSLAM_TRY(join(p * 2 * b, b, b, 1));
+        }
+        if (i0r + b < n) VSLAM_TRY(join(i0r, b, n - i0r - b, 1));
     }
     return VSLAM_OK;
 }
@@ -277,3 +295,23 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
 }
 
 }  // namespace vslam
+
+// Test hook (not part of the public header): W = S^-1 for `batch` upper-triangular n x n matrices held one after
+// the other on the host (column-major, ld n).
+extern "C" vslam_status vslam_debug_trtri(vslam_ctx *ctx, const double *S, int n, int batch, double *W)
+{
+    using namespace vslam;
+    if (!ctx || !S || !W || n < 1 || batch < 1) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, bytes = nn * batch * 8;
+    const size_t tws = batch == 1 ? trtri_ws_bytes(n) : trtri_batch_ws_bytes(n, batch);
+    VSLAM_TRY(ws_reserve(ctx, 2 * Arena::pad(bytes) + tws));
+    Arena ar(ctx->ws);
+    double *dS = ar.take<double>(nn * batch), *dW = ar.take<double>(nn * batch);
+    void *w = ar.take<char>(tws);
+    VSLAM_TRY(h2d(ctx, dS, S, bytes));
+    if (batch == 1) VSLAM_TRY(trtri_upper_dev(ctx, dS, n, n, dW, n, w));
+    else VSLAM_TRY(trtri_upper_batch_dev(ctx, dS, n, n, nn, dW, n, nn, batch, w));
+    VSLAM_TRY(d2h(ctx, W, dW, bytes));
+    return stream_finish(ctx);
+}
