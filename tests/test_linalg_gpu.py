@@ -287,3 +287,45 @@ def test_triangular_inverse_bank(ctx):
     for b in range(B):
         assert rel_err(W[b], np.linalg.inv(U[b])) <= 1e-11
         assert not np.tril(W[b], -1).any()
+
+
+def _potrf(ctx, A):
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    A = np.ascontiguousarray(A, dtype=np.float64).copy()   # symmetric input: row-major and column-major coincide
+    batch, n = (1, A.shape[0]) if A.ndim == 2 else (A.shape[0], A.shape[1])
+    info = np.full(batch, -1, dtype=np.int32)
+    fn = L.vslam_debug_potrf
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert fn(ctx.ptr, A.ctypes.data, n, batch, info.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
+    return np.swapaxes(A, -1, -2), info                    # the device wrote column-major factors
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 96, 97, 128, 130, 200, 462, 1000, 2100])
+def test_cholesky_vs_lapack(ctx, n):
+    """Blocked upper Cholesky: first block by the stand-alone kernel, later diagonal blocks by the workgroup of the
+    trailing update that produced them (trailing matrices of up to 32 rows by the stand-alone kernel again), row
+    panels by the MFMA substitution."""
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n, n + 3))
+    H = G @ G.T / n + np.eye(n)
+    U, info = _potrf(ctx, H)
+    assert info[0] == 0
+    assert not np.tril(U, -1).any()
+    assert rel_err(U, np.linalg.cholesky(H).T) <= 1e-12
+    assert rel_err(U.T @ U, H) <= 1e-13
+
+
+def test_cholesky_bank_and_indefinite_matrix(ctx):
+    rng = np.random.default_rng(5)
+    B, n = 6, 300
+    G = rng.standard_normal((B, n, n))
+    H = G @ np.transpose(G, (0, 2, 1)) / n + np.eye(n)
+    H[2, 170, 170] = -1.0                                   # pivot 171 of matrix 2 is not positive
+    H[4, 10, 10] = -50.0
+    U, info = _potrf(ctx, H)
+    assert info.tolist()[:2] == [0, 0] and info[3] == 0 and info[5] == 0
+    assert info[2] == 171 and info[4] == 11
+    for b in (0, 1, 3, 5):
+        assert rel_err(U[b], np.linalg.cholesky(H[b]).T) <= 1e-12

@@ -33,6 +33,8 @@ struct vslam_ctx {
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up; [64..320) ready
                                  // marks of the chained triangular solve (value = chain_epoch of the call)
     int chain_epoch = 0;
+    double *potf_dinv = nullptr; // device: per matrix of a blocked Cholesky, the inverses of the current diagonal block's 16 x 16 sub-blocks
+    int potf_dinv_batch = 0;
     int *flags_host = nullptr;   // pinned mirror read by stream_finish
     int trs_solver = 1;          // VSLAM_TRS_CHOLESKY (default: device route, eigenvalue route when the Hessian is indefinite) / VSLAM_TRS_EIG
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last measurement update on the device route: ms in cost evaluations, trust-region
@@ -76,6 +78,7 @@ inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
 // across a growth.  Synchronises the stream before freeing the old block.
 vslam_status ws_reserve(vslam_ctx *ctx, size_t bytes);
 vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes);
+vslam_status potf_dinv_reserve(vslam_ctx *ctx, int batch);   // ctx->potf_dinv holds 1024 doubles per matrix
 // Synchronises the context's stream and turns a raised device flag into an error.
 vslam_status stream_finish(vslam_ctx *ctx);
 // Synchronises the stream and completes the staged device-to-host copies.

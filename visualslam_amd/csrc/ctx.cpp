@@ -44,6 +44,23 @@ vslam_status scratch_reserve(vslam_ctx *ctx, size_t bytes)
     return VSLAM_OK;
 }
 
+vslam_status potf_dinv_reserve(vslam_ctx *ctx, int batch)
+{
+    if (batch <= ctx->potf_dinv_batch) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->potf_dinv) {
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        VSLAM_HIP_TRY(ctx, hipFree(ctx->potf_dinv));
+        ctx->potf_dinv = nullptr;
+        ctx->potf_dinv_batch = 0;
+    }
+    const int want = batch < 8 ? 8 : batch;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->potf_dinv), (size_t)want * 1024 * 8);
+    if (e != hipSuccess) return fail(ctx, VSLAM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", (size_t)want * 1024 * 8, hipGetErrorString(e));
+    ctx->potf_dinv_batch = want;
+    return VSLAM_OK;
+}
+
 static vslam_status pinned_take(vslam_ctx *ctx, size_t bytes, char **out)
 {
     const size_t need = (bytes + 255) & ~size_t(255);
@@ -240,6 +257,7 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->potf_dinv) (void)hipFree(ctx->potf_dinv);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);

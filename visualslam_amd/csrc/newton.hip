@@ -15,7 +15,7 @@
 // i.e. the upper-triangular S with S^T S = H^-1) is formed as the inverse of the upper-triangular M
 // with M M^T = H (a Cholesky factorisation of the index-reversed H).  It equals the reference's S up
 // to the signs of its rows, which there depend on the eigensolver's choice of eigenvector signs.
-#include "linalg.hpp"
+#include "potf.hpp"
 
 #include <chrono>
 
@@ -24,24 +24,21 @@
 
 namespace vslam {
 
-constexpr int CB = 64;           // Cholesky block
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// Upper Cholesky of the jb x jb diagonal block at (j0, j0) by one wave, the block in LDS, lane j owning
-// column j.  Rows are finished eight at a time: the eight rows first receive all finished rows above
-// them (left-looking; per finished row one own-column read and eight broadcast reads feed eight
-// multiply-adds held in registers), then are factored among themselves with lane broadcasts.  Only the
-// upper triangle is read and written.  A non-positive pivot stores its 1-based column in *info (first
-// one wins); the arithmetic carries on with NaNs.
-constexpr int PLD = CB + 2;      // even: the eight broadcast values of a row are two aligned 16-byte pairs apart
-constexpr int PR = 8;
-__global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info, size_t strideA, const int *active)
+// Upper Cholesky of the jb x jb diagonal block at (j0, j0): the block goes to LDS, one wave factors it
+// (potf2_lds), the four waves invert its 16 x 16 diagonal sub-blocks for the row-panel solve and write the
+// factor back.  Only the upper triangle is read and written.  Used for the first block of a factorisation and for
+// trailing matrices too small for the GEMM epilogue; every other diagonal block is factored by the workgroup of
+// the trailing update that produced it (gemm.hip).
+__global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info, size_t strideA, const int *active,
+                                                           double *dinv, size_t stride_dinv)
 {
-    __shared__ __align__(16) double U[CB * PLD];                  // U[l][j] at l * PLD + j
-    const int lane = threadIdx.x;
+    __shared__ __align__(16) double U[POTF_LDS_DOUBLES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (active && !active[blockIdx.y]) return;                    // instance blockIdx.y of a batch (stride strideA, one info word each)
     A += (size_t)blockIdx.y * strideA;
-    info += blockIdx.y;
-    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
+    for (int cb = 16 * wave; cb < 16 * wave + 16; cb += 16) {      // lane = row: coalesced column reads, 16 in flight
         double v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j)
@@ -50,73 +47,68 @@ __global__ __launch_bounds__(64) void potf2_upper_kernel(double *A, int lda, int
         for (int j = 0; j < 16; ++j) U[lane * PLD + cb + j] = v[j];
     }
     __syncthreads();
-    bool bad = false;
-    for (int kb = 0; kb < CB; kb += PR) {
-        double acc[PR];
-#pragma unroll
-        for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
-#pragma unroll 4
-        for (int l = 0; l < kb; ++l) {
-            const double own = U[l * PLD + lane];
-            const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb);
-            const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
-            acc[0] -= b0.x * own; acc[1] -= b0.y * own; acc[2] -= b1.x * own; acc[3] -= b1.y * own;
-            acc[4] -= b2.x * own; acc[5] -= b2.y * own; acc[6] -= b3.x * own; acc[7] -= b3.y * own;
-        }
-#pragma unroll
-        for (int r = 0; r < PR; ++r) {
-            const int row = kb + r;
-            const double dkk = readlane_f64(acc[r], row);
-            if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
-            const double inv = rsqrt(dkk);                       // one reciprocal square root per row instead of a square root and a division
-            const double u = (lane == row) ? dkk * inv : acc[r] * inv;     // row `row` of U (meaningful for lanes >= row)
-            U[row * PLD + lane] = u;
-#pragma unroll
-            for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
-        }
-    }
+    if (wave == 0) potf2_lds(U, U + CB * PLD, jb, j0, info + blockIdx.y);
     __syncthreads();
-#pragma unroll 8
-    for (int c = 0; c < jb; ++c)
+    potf_dinv16(U, U + CB * PLD, dinv + (size_t)blockIdx.y * stride_dinv);
+    for (int c = wave; c < jb; c += 4)
         if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * PLD + c];
 }
 
-// Row panel of the factor: X = U_JJ^-T * A[J, rest] in place.  A workgroup (one wave) owns 64
-// columns; lane = column with its 64 entries in registers, forward substitution
-// x_k = (b_k - sum_{l<k} U[l][k] x_l) / U[k][k] with U read from LDS (the same address in every lane).
-constexpr int CLD = CB + 2;
-__global__ __launch_bounds__(64) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active)
+// Row panel of the factor: X = U_JJ^-T * A[J, rest] in place, on the matrix cores.  A workgroup owns 64 columns,
+// a wave 16 of them; the 64 x 16 right-hand side of a wave lives in registers as four 16 x 16 blocks in the
+// accumulator layout of v_mfma_f64_16x16x4_f64, which is also the layout of its B operand, so the blocked forward
+// substitution
+//     X_i = (U_ii)^-T R_i,     R_j -= (U_ij)^T X_i   (j > i)
+// is a chain of MFMA groups with no shuffles in between.  (U_ii)^-T comes from the factorisation of the diagonal
+// block (potf_dinv16), U_ij from the factored block itself.
+constexpr int TLD = 17;          // row stride of the 16 x 16 inverses in LDS
+__global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active,
+                                                          const double *dinv, size_t stride_dinv)
 {
-    __shared__ __align__(16) double Ut[CB * CLD];                 // Ut[k][l] = U[l][k]: column k contiguous in l
-    const int lane = threadIdx.x;
+    __shared__ __align__(16) double U[CB * PLD];                   // U[l][j] at l * PLD + j (upper triangle meaningful)
+    __shared__ double Yt[4 * 16 * TLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
     if (active && !active[blockIdx.y]) return;
     A += (size_t)blockIdx.y * strideA;
-    const int c0 = j0 + CB + blockIdx.x * CB, nc = min(CB, n - c0);
-    for (int cb = 0; cb < CB; cb += 16) {                          // lane = row: coalesced column reads, 16 in flight
-        double u[16];
+    dinv += (size_t)blockIdx.y * stride_dinv;
+    const int c0 = j0 + CB + blockIdx.x * CB;
+    const int col = c0 + 16 * wave + l15;
+    const bool cok = col < n;
+    // right-hand side: block bi, register q <-> row 16 bi + 4 q + kr of this lane's column
+    double4_t R[4];
+    const double *colp = A + (size_t)(cok ? col : c0) * lda + j0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) u[j] = (lane <= cb + j) ? A[(size_t)(j0 + cb + j) * lda + j0 + lane] : 0.0;
+    for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Ut[(cb + j) * CLD + lane] = u[j];
+        for (int q = 0; q < 4; ++q) R[bi][q] = cok ? colp[16 * bi + 4 * q + kr] : 0.0;
+    {
+        double v[16];                                              // lane = row: coalesced column reads, 16 in flight
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (lane <= 16 * wave + j) ? A[(size_t)(j0 + 16 * wave + j) * lda + j0 + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) U[lane * PLD + 16 * wave + j] = v[j];
+        for (int e = tid; e < 1024; e += 256) Yt[(e >> 4) * TLD + (e & 15)] = dinv[e];
     }
-    __shared__ double rdiag[CB];
-    double x[CB];
-    double *colx = A + (size_t)(c0 + (lane < nc ? lane : 0)) * lda + j0;
-#pragma unroll
-    for (int k = 0; k < CB; ++k) x[k] = colx[k];
-    __syncthreads();
-    rdiag[lane] = 1.0 / Ut[lane * CLD + lane];                  // all 64 reciprocals at once: the chain below only multiplies
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < CB; ++k) {
-        double s = x[k];
+    for (int bi = 0; bi < 4; ++bi) {
+        double4_t X = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int l = 0; l < k; ++l) s -= Ut[k * CLD + l] * x[l];
-        x[k] = s * rdiag[k];
+        for (int k0 = 0; k0 < 16; k0 += 4)
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(16 * bi + l15) * TLD + k0 + kr], R[bi][k0 >> 2], X, 0, 0, 0);
+        R[bi] = X;
+#pragma unroll
+        for (int bj = bi + 1; bj < 4; ++bj)
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4)
+                R[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(16 * bi + k0 + kr) * PLD + 16 * bj + l15], X[k0 >> 2], R[bj], 0, 0, 0);
     }
-    if (lane < nc) {
+    if (cok) {
+        double *outp = A + (size_t)col * lda + j0;
 #pragma unroll
-        for (int k = 0; k < CB; ++k) colx[k] = x[k];
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) outp[16 * bi + 4 * q + kr] = R[bi][q];
     }
 }
 
@@ -147,12 +139,15 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
                                    bool zero_lower)
 {
     hipStream_t s = ctx->stream;
+    VSLAM_TRY(potf_dinv_reserve(ctx, batch));
+    double *dinv = ctx->potf_dinv;
+    bool factored = false;                            // the diagonal block of this step was factored by the previous update
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
-        hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(64), 0, s, A, lda, j0, jb, info, strideA, active);
+        if (!factored) hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(256), 0, s, A, lda, j0, jb, info, strideA, active, dinv, (size_t)1024);
         const int rest = n - j0 - jb;
         if (rest <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB, batch), dim3(64), 0, s, A, lda, n, j0, strideA, active);
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, dinv, (size_t)1024);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         GemmDesc g;                                   // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
         g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0; g.c_upper = true;
@@ -160,6 +155,8 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
         g.B = g.A; g.ldb = lda; g.strideB = strideA;
         g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda; g.strideC = strideA;
         g.batch = batch; g.active = active;
+        factored = rest > 32;                         // the update's workgroup for the next diagonal tile factors it as well
+        if (factored) { g.potf_dinv = dinv; g.stride_dinv = 1024; g.potf_info = info; g.potf_j0 = j0 + jb; }
         VSLAM_TRY(gemm_f64(ctx, g));
     }
     if (!zero_lower) return VSLAM_OK;
@@ -368,3 +365,24 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
 }
 
 }  // namespace vslam
+
+// Test hook (not part of the public header): in-place upper Cholesky factors of `batch` symmetric n x n matrices held
+// one after the other on the host (column-major, ld n; only the upper triangles are read); info[b] = 0 or the
+// 1-based column of the first non-positive pivot.
+extern "C" vslam_status vslam_debug_potrf(vslam_ctx *ctx, double *A, int n, int batch, int *info)
+{
+    using namespace vslam;
+    if (!ctx || !A || !info || n < 1 || batch < 1) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, bytes = nn * batch * 8;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(bytes) + Arena::pad((size_t)batch * sizeof(int))));
+    Arena ar(ctx->ws);
+    double *dA = ar.take<double>(nn * batch);
+    int *dinfo = ar.take<int>(batch);
+    VSLAM_TRY(h2d(ctx, dA, A, bytes));
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(dinfo, 0, (size_t)batch * sizeof(int), ctx->stream));
+    VSLAM_TRY(potrf_upper_batch_dev(ctx, dA, n, n, nn, batch, dinfo, nullptr));
+    VSLAM_TRY(d2h(ctx, A, dA, bytes));
+    VSLAM_TRY(d2h(ctx, info, dinfo, (size_t)batch * sizeof(int)));
+    return stream_finish(ctx);
+}
