@@ -15,6 +15,8 @@
 // A device-to-host copy staged in pinned memory, finished (pinned -> caller's buffer) after the stream drains.
 struct vslam_pending_copy { void *dst; const void *src; size_t width, height, dpitch; };
 
+constexpr int VSLAM_CHAIN_SOL_DOUBLES = 240 * 64;   // the chained triangular solve handles up to 240 blocks of 64
+
 struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -30,9 +32,8 @@ struct vslam_ctx {
     bool failed = false;         // an entry point returned an error: its staged copies are dropped, not completed
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up; [64..320) ready
-                                 // marks of the chained triangular solve (value = chain_epoch of the call)
-    int chain_epoch = 0;
+    int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up
+    double *chain_sol = nullptr; // device: solution blocks of the chained triangular solve as its workgroups publish them
     double *potf_dinv = nullptr; // device: per matrix of a blocked Cholesky, the inverses of the current diagonal block's 16 x 16 sub-blocks
     int potf_dinv_batch = 0;
     int *flags_host = nullptr;   // pinned mirror read by stream_finish

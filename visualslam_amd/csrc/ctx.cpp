@@ -229,6 +229,7 @@ static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **
         c->own_stream = true;
     }
     if (hipMalloc(reinterpret_cast<void **>(&c->flags), 320 * sizeof(int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->chain_sol), (size_t)VSLAM_CHAIN_SOL_DOUBLES * 8) != hipSuccess ||
         hipMemset(c->flags, 0, 320 * sizeof(int)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         vslam_ctx_destroy(c);
@@ -263,6 +264,7 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 3; ++i) if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
     if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->chain_sol) (void)hipFree(ctx->chain_sol);
     if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

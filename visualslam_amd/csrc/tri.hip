@@ -193,12 +193,17 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
 // The same solve in ONE launch for up to TC_MAX diagonal blocks: workgroup i owns the i-th block in
 // dependency order (trans: first to last; otherwise last to first).  It adds up the contributions of the
 // blocks before it as their solutions appear (coefficients are fetched ahead of the wait: they do not
-// depend on it), solves its own 64 x 64 block in one wave and publishes the 64 entries followed by a
-// ready mark.  Only the chain of diagonal solves is sequential; the off-diagonal work of all
-// workgroups overlaps it.  All workgroups are resident together (TC_MAX <= 240 of 256 threads), a wait
-// that exceeds its bound raises *err and lets every wave run to the end.
+// depend on it), solves its own 64 x 64 block in one wave and publishes the 64 entries.  Only the chain of
+// diagonal solves is sequential; the off-diagonal work of all workgroups overlaps it.
+// A solution entry is its own ready mark: `sol` is filled with a NaN of all-ones bits before the launch and a
+// reader polls the entries it needs until none of them carries that pattern any more, so a link of the chain costs
+// one trip through memory (the entries themselves), not a flag and then the data.  (A solution that is itself this
+// NaN -- only a right-hand side holding the same pattern produces one -- ends in the bounded wait below.)
+// All workgroups are resident together (TC_MAX <= 240 of 256 compute units), a wait that exceeds its bound raises
+// *err and lets every wave run to the end.
 constexpr int TC_MAX = 240;
-__global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n, int ldS, int trans, double *z, int *ready, int epoch, int *err)
+static_assert(TC_MAX * TBK <= VSLAM_CHAIN_SOL_DOUBLES, "solution buffer of the context");
+__global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n, int ldS, int trans, double *z, double *sol, int *err)
 {
     __shared__ double U[TBK][TBK + 1];
     __shared__ double part[4][TBK];
@@ -233,8 +238,17 @@ __global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n,
             // trans: U(j, i0 + c)  (rows of the earlier block, own column);  otherwise U(i0 + c, j)
             coef[e] = (c < ib && j < n) ? (trans ? S[(size_t)(i0 + c) * ldS + j] : S[(size_t)j * ldS + i0 + c]) : 0.0;
         }
+        double zv[16];
         unsigned spins = 0;
-        while (!dead && __hip_atomic_load(&ready[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int j = min(v0 + 16 * p + e, n - 1);
+                zv[e] = __hip_atomic_load(&sol[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (__double_as_longlong(zv[e]) != -1ll);
+            }
+            if (ok || dead) break;
             if ((++spins & 255u) == 0) {
                 if (spins > (1u << 22)) atomicExch(err, 1);
                 if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
@@ -242,8 +256,7 @@ __global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n,
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            if (v0 + 16 * p + e < n) acc += coef[e] * __hip_atomic_load(&z[v0 + 16 * p + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = 0; e < 16; ++e) acc += coef[e] * zv[e];      // coefficients beyond the matrix are zero
     }
     part[p][c] = acc;
     __syncthreads();
@@ -266,9 +279,10 @@ __global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n,
                 else if (tid == k) v = xk;
             }
         }
-        if (tid < ib) __hip_atomic_store(&z[i0 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (tid == 0) __hip_atomic_store(&ready[w], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < ib) {
+            __hip_atomic_store(&sol[i0 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z[i0 + tid] = v;                                         // nobody else reads or writes this block of z
+        }
     }
 }
 
@@ -278,8 +292,8 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
     if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     const int nblk = (n + TBK - 1) / TBK;
     if (nblk > 1 && nblk <= TC_MAX) {
-        ctx->chain_epoch = ctx->chain_epoch == 0x7fffffff ? 1 : ctx->chain_epoch + 1;
-        hipLaunchKernelGGL(trsv_chain_kernel, dim3(nblk), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, z, ctx->flags + 64, ctx->chain_epoch, ctx->flags);
+        VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, (size_t)n * 8, s));
+        hipLaunchKernelGGL(trsv_chain_kernel, dim3(nblk), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, z, ctx->chain_sol, ctx->flags);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     }
