@@ -302,11 +302,12 @@ def _potrf(ctx, A):
     return np.swapaxes(A, -1, -2), info                    # the device wrote column-major factors
 
 
-@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 96, 97, 128, 130, 200, 462, 1000, 2100])
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 96, 97, 128, 130, 160, 161, 192, 193, 200, 224, 225, 256, 462, 1000, 2100])
 def test_cholesky_vs_lapack(ctx, n):
     """Blocked upper Cholesky: first block by the stand-alone kernel, later diagonal blocks by the workgroup of the
     trailing update that produced them (trailing matrices of up to 32 rows by the stand-alone kernel again), row
-    panels by the MFMA substitution."""
+    panels by the MFMA substitution, two block rows per pass over the trailing matrix; the sizes end a
+    factorisation in every position of that two-row step."""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n + 3))
     H = G @ G.T / n + np.eye(n)

@@ -25,7 +25,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int BK = 16;
 
 struct GemmArgs {
-    int M, N, K, lda, ldb, ldc, amode, b_upper, kchunk, tilesM, c_upper;
+    int M, N, K, lda, ldb, ldc, amode, b_upper, kchunk, tilesM, tilesN, c_upper;
     double alpha, beta;
     const double *A, *B;
     double *C;
@@ -33,6 +33,35 @@ struct GemmArgs {
     const int *active;
     double *pf_dinv; size_t pf_sdinv; int *pf_info; int pf_j0;     // factor the tile (0, 0) of C after its update (potf.hpp)
 };
+
+// Tiles (tm, tn) of a BM x BN tiling that touch the upper triangle (tm BM <= tn BN + BN - 1), enumerated in bands of
+// eight tile rows, each band column by column from its first such column on.  count_only: the number of tiles.
+__host__ __device__ inline int upper_tile_walk(int l, int tilesM, int tilesN, int BM, int BN, int *tm_out, int *tn_out)
+{
+    int total = 0;
+    for (int r0 = 0; r0 < tilesM; r0 += 8) {
+        const int rows = (tilesM - r0) < 8 ? (tilesM - r0) : 8;
+        int tn = (r0 * BM) / BN;                                   // first column whose tile (r0, tn) touches the triangle
+        for (; tn < tilesN; ++tn) {                                // head of the band: columns that hold fewer than `rows` tiles
+            const int tmax = (tn * BN + BN - 1) / BM;
+            const int c = (tmax - r0 + 1) < rows ? (tmax - r0 + 1) : rows;
+            if (c == rows) break;
+            if (l >= 0 && l < c) { *tm_out = r0 + l; *tn_out = tn; return -1; }
+            if (l >= 0) l -= c;
+            total += c;
+        }
+        const int full = (tilesN - tn) * rows;                     // the rest of the band: `rows` tiles per column
+        if (l >= 0 && l < full) { *tm_out = r0 + l % rows; *tn_out = tn + l / rows; return -1; }
+        if (l >= 0) l -= full;
+        total += full;
+    }
+    return total;
+}
+__device__ __forceinline__ void upper_tile_of(int l, int tilesM, int tilesN, int BM, int BN, int *tm, int *tn)
+{
+    *tm = 0; *tn = 0;
+    upper_tile_walk(l, tilesM, tilesN, BM, BN, tm, tn);
+}
 
 template <bool TA>
 __device__ __forceinline__ double fetch_a(const GemmArgs &g, const double *A, int m, int k)
@@ -67,20 +96,22 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Tile order.  Workgroup ids are dealt round-robin to the eight XCDs (an L2 each): renumbered so that an XCD works
-    // through one contiguous run of tiles, and the tiles ordered in groups of eight tile rows swept along N, so that
+    // through one contiguous run of tiles, and the tiles ordered in bands of eight tile rows swept along N, so that
     // the tiles an XCD has in flight share a few row blocks of A and column blocks of B that stay in its L2.
-    // (Not for the triangular updates: their empty tiles below the diagonal would gather on a few XCDs.)
-    int tile_m = blockIdx.x % g.tilesM, tile_n = blockIdx.x / g.tilesM;
-    if (!g.c_upper) {
+    // A triangular update launches workgroups for the tiles that touch the upper triangle only, in the same order.
+    int tile_m, tile_n;
+    {
         const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, q = nb >> 3, r = nb & 7;
         const int l = x * q + min(x, r) + ((int)blockIdx.x >> 3);
-        const int tilesN = nb / g.tilesM, per_group = 8 * tilesN, group = l / per_group, first_m = group * 8;
-        const int gsz = min(8, g.tilesM - first_m), in_group = l - group * per_group;
-        tile_m = first_m + in_group % gsz;
-        tile_n = in_group / gsz;
+        if (g.c_upper) upper_tile_of(l, g.tilesM, g.tilesN, BM, BN, &tile_m, &tile_n);
+        else {
+            const int per_group = 8 * g.tilesN, group = l / per_group, first_m = group * 8;
+            const int gsz = min(8, g.tilesM - first_m), in_group = l - group * per_group;
+            tile_m = first_m + in_group % gsz;
+            tile_n = in_group / gsz;
+        }
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    if (g.c_upper && m0 > n0 + BN - 1) return;             // tile entirely below the diagonal of C: not wanted
     const int split = blockIdx.y, b = blockIdx.z;
     if (g.active && !g.active[b]) return;
     const double *A = g.A + (size_t)b * g.sA;
@@ -252,8 +283,10 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream)
     const bool smallM = d.M <= 32;
     const int bm = smallM ? 32 : 64, bn = 64;
     a.tilesM = (d.M + bm - 1) / bm;
-    const int tilesN = (d.N + bn - 1) / bn;
-    dim3 grid(a.tilesM * tilesN, d.ksplit, d.batch);
+    a.tilesN = (d.N + bn - 1) / bn;
+    int tmp_m = 0, tmp_n = 0;
+    const int tiles = d.c_upper ? upper_tile_walk(-1, a.tilesM, a.tilesN, bm, bn, &tmp_m, &tmp_n) : a.tilesM * a.tilesN;
+    dim3 grid(tiles, d.ksplit, d.batch);
     if (smallM) launch<32, 64>(a, grid, stream, d.transA, d.transB);
     else launch<64, 64>(a, grid, stream, d.transA, d.transB);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
