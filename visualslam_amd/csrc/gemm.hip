@@ -16,7 +16,7 @@
 // result index n, columns index m) so that the 16 lanes sharing an accumulator
 // register hold 16 consecutive rows of one C column: stores are 128-byte
 // contiguous segments of the column-major C.
-#include "potf.hpp"
+#include "linalg.hpp"
 
 namespace vslam {
 
@@ -31,7 +31,6 @@ struct GemmArgs {
     double *C;
     size_t sA, sB, sC, sSplit;
     const int *active;
-    double *pf_dinv; size_t pf_sdinv; int *pf_info; int pf_j0;     // factor the tile (0, 0) of C after its update (potf.hpp)
 };
 
 // Tiles (tm, tn) of a BM x BN tiling that touch the upper triangle (tm BM <= tn BN + BN - 1), enumerated in bands of
@@ -212,32 +211,6 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     }
     // acc[i][j][r] = C[m0+wm+16i+(lane&15)][n0+wn+16j+(lane>>4)+4r]
     const bool split_mode = gridDim.y > 1;
-    if constexpr (BM == 64 && BN == 64 && TA && !TB) {
-        // Blocked Cholesky: the workgroup of the next diagonal tile factors it right here, while the other
-        // workgroups of the launch are still updating the rest of the trailing matrix.
-        if (g.pf_dinv && m0 == 0 && n0 == 0 && !split_mode) {
-            static_assert(2 * BK * LDA_S + 2 * BK * LDB_S >= POTF_LDS_DOUBLES, "the staging buffers hold the diagonal block");
-            double *U = smem, *invd = smem + CB * PLD;         // every wave is past the last K-step's barrier
-            const int jb = min(CB, g.N);
-#pragma unroll
-            for (int i = 0; i < TMw; ++i)
-#pragma unroll
-                for (int j = 0; j < TNw; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = wm + 16 * i + (lane & 15), n = wn + 16 * j + (lane >> 4) + 4 * r;
-                        const double v = rmw ? g.alpha * acc[i][j][r] + g.beta * cold[i][j][r] : g.alpha * acc[i][j][r];
-                        U[m * PLD + n] = (m <= n && n < jb) ? v : (m == n ? 1.0 : 0.0);
-                    }
-            __syncthreads();
-            if (wave == 0) potf2_lds(U, invd, jb, g.pf_j0, g.pf_info + b);
-            __syncthreads();
-            potf_dinv16(U, invd, g.pf_dinv + (size_t)b * g.pf_sdinv);
-            for (int c = wave; c < jb; c += 4)
-                if (lane <= c) C[(size_t)c * g.ldc + lane] = U[lane * PLD + c];
-            return;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < TMw; ++i)
 #pragma unroll
@@ -274,9 +247,6 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream)
     a.amode = (int)d.amode; a.b_upper = d.b_upper ? 1 : 0; a.c_upper = d.c_upper ? 1 : 0;
     a.alpha = d.alpha; a.beta = d.beta; a.A = d.A; a.B = d.B; a.C = d.C;
     a.sA = d.strideA; a.sB = d.strideB; a.sC = d.strideC; a.sSplit = d.strideSplit; a.active = d.active;
-    a.pf_dinv = d.potf_dinv; a.pf_sdinv = d.stride_dinv; a.pf_info = d.potf_info; a.pf_j0 = d.potf_j0;
-    if (d.potf_dinv && !(d.transA && !d.transB && d.M > 32 && d.ksplit == 1 && d.potf_info))
-        return fail(ctx, VSLAM_ERR_ARG, "gemm: the diagonal-tile factorisation goes with the A^T B update of at least 33 rows");
     int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
     kchunk = ((kchunk + BK - 1) / BK) * BK;
     a.kchunk = kchunk > 0 ? kchunk : BK;

@@ -58,10 +58,6 @@ struct GemmDesc {
     const int *active = nullptr;   // device, optional: batch members whose entry is 0 are skipped
     int ksplit = 1;          // >1: split K; slab s of batch b is written (beta ignored) at
     size_t strideSplit = 0;  //     C + b*strideC + s*strideSplit
-    // Blocked Cholesky (transA, !transB, M > 32): the workgroup of tile (0, 0) of C factors the updated tile in place
-    // (upper Cholesky, potf.hpp) and leaves the inverses of its four 16 x 16 diagonal sub-blocks at
-    // potf_dinv + b*stride_dinv (1024 doubles); a non-positive pivot at row r stores potf_j0 + r + 1 in potf_info[b].
-    double *potf_dinv = nullptr; size_t stride_dinv = 0; int *potf_info = nullptr; int potf_j0 = 0;
 };
 
 // C = alpha * op(A) * op(B) + beta * C on v_mfma_f64_16x16x4_f64.

@@ -112,6 +112,146 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int
     }
 }
 
+// Trailing update of the factorisation: C (N x N, its origin on the diagonal of the matrix; the tiles that touch
+// the upper triangle) -= P^T P, P = the K finished rows above C, which lie contiguously in every column.  One
+// workgroup per 64 x 64 tile of the upper triangle (no workgroups for the others).  At K = 64 the launch is bound by
+// the read-modify-write of C and by the matrix cores in about equal parts, so the kernel is kept minimal: the old
+// tile is requested first, P goes through LDS sixteen rows at a time with plain indexing (row stride 18 doubles:
+// the 32 lanes of a read phase cover all banks), four workgroups per compute unit cover one another's waits.
+// The workgroup of tile (0, 0) then factors its tile -- the next diagonal block (potf.hpp) -- while the rest of the
+// launch is still updating.
+struct CholUpdArgs {
+    const double *P;               // element (first finished row, first column of C)
+    double *C;                     // element (0, 0) of the trailing block
+    int N, K, lda;
+    size_t strideA;
+    const int *active;
+    double *dinv; size_t stride_dinv; int *info; int j0;
+};
+constexpr int UKC = 16, ULD = UKC + 2;
+// linear id -> tile (tm <= tn) of the upper triangle, column by column
+__device__ __forceinline__ void upper_tile(int l, int *tm, int *tn)
+{
+    int n = (int)((sqrtf(8.0f * (float)l + 1.0f) - 1.0f) * 0.5f);
+    while ((n + 1) * (n + 2) / 2 <= l) ++n;
+    while (n * (n + 1) / 2 > l) --n;
+    *tn = n; *tm = l - n * (n + 1) / 2;
+}
+__global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
+{
+    __shared__ __align__(16) double Ps[POTF_LDS_DOUBLES];             // operand chunks; afterwards the diagonal block of tile (0, 0)
+    static_assert(2 * CB * ULD <= POTF_LDS_DOUBLES, "operand chunks fit");
+    double *const Pm = Ps, *const Pn = Ps + CB * ULD;                 // [column of the tile][row of the chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
+    const int b = blockIdx.y;
+    if (g.active && !g.active[b]) return;
+    int tile_m, tile_n;
+    upper_tile(blockIdx.x, &tile_m, &tile_n);
+    const int m0 = tile_m * CB, n0 = tile_n * CB;
+    const double *P = g.P + (size_t)b * g.strideA;
+    double *C = g.C + (size_t)b * g.strideA;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const bool diag = m0 == n0;
+    // old values of the tile, in the accumulator layout: [i][j][r] <-> row m0+wm+16i+l15, column n0+wn+16j+kr+4r
+    double cold[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(m0 + wm + 16 * i + l15, g.N - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, g.N - 1);
+                cold[i][j][r] = C[(size_t)n * g.lda + m];
+            }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double *Bn = diag ? Pm : Pn;
+    if (blockIdx.x == 0 && g.K <= CB) {
+        // tile (0, 0) heads the chain of diagonal blocks: its K x 64 operand in one trip through memory
+        // (lane = row, a wave fetches whole columns), then the products straight through
+        double ra[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ra[e] = lane < g.K ? P[(size_t)min(wave + 4 * e, g.N - 1) * g.lda + lane] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Ps[(wave + 4 * e) * PLD + lane] = ra[e];
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < CB; kk += 4) {
+            double am[2], bn[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) am[i] = Ps[(wm + 16 * i + l15) * PLD + kk + kr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bn[j] = Ps[(wn + 16 * j + l15) * PLD + kk + kr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+    } else
+    for (int k0 = 0; k0 < g.K; k0 += UKC) {
+        double ra[4], rb[4];                                        // thread: row tid % 16 of the chunk, columns tid / 16 + 16 e
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid >> 4) + 16 * e, kk = tid & 15;
+            ra[e] = P[(size_t)min(m0 + c, g.N - 1) * g.lda + k0 + kk];
+            if (!diag) rb[e] = P[(size_t)min(n0 + c, g.N - 1) * g.lda + k0 + kk];
+        }
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid >> 4) + 16 * e, kk = tid & 15;
+            Pm[c * ULD + kk] = ra[e];
+            if (!diag) Pn[c * ULD + kk] = rb[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < UKC; kk += 4) {
+            double am[2], bn[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) am[i] = Pm[(wm + 16 * i + l15) * ULD + kk + kr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bn[j] = Bn[(wn + 16 * j + l15) * ULD + kk + kr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (blockIdx.x == 0) {                                          // tile (0, 0): the next diagonal block
+        __syncthreads();
+        double *U = Ps, *invd = Ps + CB * PLD;
+        const int jb = min(CB, g.N);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = wm + 16 * i + l15, n = wn + 16 * j + kr + 4 * r;
+                    U[m * PLD + n] = (m <= n && n < jb) ? cold[i][j][r] - acc[i][j][r] : (m == n ? 1.0 : 0.0);
+                }
+        __syncthreads();
+        if (wave == 0) potf2_lds(U, invd, jb, g.j0, g.info + b);
+        __syncthreads();
+        potf_dinv16(U, invd, g.dinv + (size_t)b * g.stride_dinv);
+        for (int c = wave; c < jb; c += 4)
+            if (lane <= c) C[(size_t)c * g.lda + lane] = U[lane * PLD + c];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + l15, n = n0 + wn + 16 * j + kr + 4 * r;
+                if (m < g.N && n < g.N) C[(size_t)n * g.lda + m] = cold[i][j][r] - acc[i][j][r];
+            }
+}
+
 __global__ void add_diag_kernel(double *A, int lda, int n, double lam)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,15 +289,13 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
         if (rest <= 0) break;
         hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, dinv, (size_t)1024);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        GemmDesc g;                                   // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
-        g.M = rest; g.N = rest; g.K = jb; g.transA = true; g.transB = false; g.alpha = -1.0; g.beta = 1.0; g.c_upper = true;
-        g.A = A + (size_t)(j0 + jb) * lda + j0; g.lda = lda; g.strideA = strideA;
-        g.B = g.A; g.ldb = lda; g.strideB = strideA;
-        g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.ldc = lda; g.strideC = strideA;
-        g.batch = batch; g.active = active;
-        factored = rest > 32;                         // the update's workgroup for the next diagonal tile factors it as well
-        if (factored) { g.potf_dinv = dinv; g.stride_dinv = 1024; g.potf_info = info; g.potf_j0 = j0 + jb; }
-        VSLAM_TRY(gemm_f64(ctx, g));
+        CholUpdArgs g;                                // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
+        g.P = A + (size_t)(j0 + jb) * lda + j0; g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.N = rest; g.K = jb; g.lda = lda;
+        g.strideA = strideA; g.active = active; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
+        const int T = (rest + CB - 1) / CB;
+        hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2, batch), dim3(256), 0, s, g);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        factored = true;                              // the update's workgroup for the next diagonal tile factors it as well
     }
     if (!zero_lower) return VSLAM_OK;
     const size_t zblocks = ((size_t)n * n + 4095) / 4096;

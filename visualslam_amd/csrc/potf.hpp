@@ -12,6 +12,15 @@ constexpr int PLD = CB + 2;      // row stride of the block in LDS; even: the ei
 constexpr int PR = 8;
 constexpr int POTF_LDS_DOUBLES = CB * PLD + CB;       // the block, then 1 / U_kk
 
+// 1 / sqrt(d) from the hardware estimate (about 2^-26 relative) and one third-order correction
+// y <- y + y e/2 (1 + 3e/4), e = 1 - d y^2: full double precision in five operations on the pivot chain.
+__device__ __forceinline__ double potf_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * y, e = fma(-d * y, y, 1.0);
+    return fma(h * e, fma(0.75, e, 1.0), y);
+}
+
 // One wave: upper Cholesky factor of the 64 x 64 block U (LDS, U[l][j] at l * PLD + j, identity beyond the
 // matrix), in place, lane j owning column j.  Rows are finished eight at a time: the eight rows first receive all
 // finished rows above them (left-looking; per finished row one own-column read and eight broadcast reads feed
