@@ -289,33 +289,40 @@ def test_triangular_inverse_bank(ctx):
         assert not np.tril(W[b], -1).any()
 
 
-def _potrf(ctx, A):
+def _potrf(ctx, A, rhs=None):
     from visualslam_amd import _lib
     L = _lib.lib()
     A = np.ascontiguousarray(A, dtype=np.float64).copy()   # symmetric input: row-major and column-major coincide
     batch, n = (1, A.shape[0]) if A.ndim == 2 else (A.shape[0], A.shape[1])
     info = np.full(batch, -1, dtype=np.int32)
+    r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64).copy()
     fn = L.vslam_debug_potrf
     fn.restype = C.c_int32
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-    assert fn(ctx.ptr, A.ctypes.data, n, batch, info.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
-    return np.swapaxes(A, -1, -2), info                    # the device wrote column-major factors
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert fn(ctx.ptr, A.ctypes.data, n, batch, info.ctypes.data, None if r is None else r.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
+    U = np.swapaxes(A, -1, -2)                              # the device wrote column-major factors
+    return (U, info) if rhs is None else (U, info, r)
 
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 96, 97, 128, 130, 160, 161, 192, 193, 200, 224, 225, 256, 462, 1000, 2100])
 def test_cholesky_vs_lapack(ctx, n):
     """Blocked upper Cholesky: first block by the stand-alone kernel, later diagonal blocks by the workgroup of the
-    trailing update that produced them (trailing matrices of up to 32 rows by the stand-alone kernel again), row
-    panels by the MFMA substitution, two block rows per pass over the trailing matrix; the sizes end a
-    factorisation in every position of that two-row step."""
+    trailing update that produced them, row panels by the MFMA substitution; the sizes end a factorisation in every
+    position of a block step.  With a right-hand side riding along as one more column, it returns as U^-T r
+    (in a tile column of its own when the trailing block fills its tiles, inside the last tile column otherwise)."""
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n + 3))
     H = G @ G.T / n + np.eye(n)
     U, info = _potrf(ctx, H)
     assert info[0] == 0
     assert not np.tril(U, -1).any()
-    assert rel_err(U, np.linalg.cholesky(H).T) <= 1e-12
+    U0 = np.linalg.cholesky(H).T
+    assert rel_err(U, U0) <= 1e-12
     assert rel_err(U.T @ U, H) <= 1e-13
+    r = rng.standard_normal(n)
+    U2, info2, t = _potrf(ctx, H, r)
+    assert info2[0] == 0 and np.array_equal(U2, U)
+    assert rel_err(t, np.linalg.solve(U0.T, r)) <= 1e-12
 
 
 def test_cholesky_bank_and_indefinite_matrix(ctx):
@@ -325,8 +332,11 @@ def test_cholesky_bank_and_indefinite_matrix(ctx):
     H = G @ np.transpose(G, (0, 2, 1)) / n + np.eye(n)
     H[2, 170, 170] = -1.0                                   # pivot 171 of matrix 2 is not positive
     H[4, 10, 10] = -50.0
-    U, info = _potrf(ctx, H)
+    r = rng.standard_normal((B, n))
+    U, info, t = _potrf(ctx, H, r)
     assert info.tolist()[:2] == [0, 0] and info[3] == 0 and info[5] == 0
     assert info[2] == 171 and info[4] == 11
     for b in (0, 1, 3, 5):
-        assert rel_err(U[b], np.linalg.cholesky(H[b]).T) <= 1e-12
+        U0 = np.linalg.cholesky(H[b]).T
+        assert rel_err(U[b], U0) <= 1e-12
+        assert rel_err(t[b], np.linalg.solve(U0.T, r[b])) <= 1e-12

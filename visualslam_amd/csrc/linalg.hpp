@@ -118,8 +118,10 @@ inline bool trs_multiplier_settled(double ff, double Delta) { return std::fabs(f
 
 size_t newton_ws_bytes(int n);
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
+// rhs (optional, one n-vector per matrix, stride_rhs apart): on return U^-T rhs -- the forward substitution rides
+// along with the factorisation as one more column of the row-panel solves and trailing updates.
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower = true);
+                                   bool zero_lower = true, double *rhs = nullptr, size_t stride_rhs = 0);
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
                                 int *status_out);

@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, in
 // is a chain of MFMA groups with no shuffles in between.  (U_ii)^-T comes from the factorisation of the diagonal
 // block (potf_dinv16), U_ij from the factored block itself.
 constexpr int TLD = 17;          // row stride of the 16 x 16 inverses in LDS
+// A right-hand side vector (R, one per matrix) rides along as column n: when the factorisation ends it holds U^-T r.
 __global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active,
-                                                          const double *dinv, size_t stride_dinv)
+                                                          const double *dinv, size_t stride_dinv, double *R, size_t strideR)
 {
     __shared__ __align__(16) double U[CB * PLD];                   // U[l][j] at l * PLD + j (upper triangle meaningful)
     __shared__ double Yt[4 * 16 * TLD];
@@ -71,20 +72,21 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int
     if (active && !active[blockIdx.y]) return;
     A += (size_t)blockIdx.y * strideA;
     dinv += (size_t)blockIdx.y * stride_dinv;
-    const int c0 = j0 + CB + blockIdx.x * CB;
+    const int jb = min(CB, n - j0);                                // the last block row may be short (then only R is to its right)
+    const int c0 = j0 + jb + blockIdx.x * CB;
     const int col = c0 + 16 * wave + l15;
-    const bool cok = col < n;
+    const bool cok = col < n + (R ? 1 : 0);
     // right-hand side: block bi, register q <-> row 16 bi + 4 q + kr of this lane's column
-    double4_t R[4];
-    const double *colp = A + (size_t)(cok ? col : c0) * lda + j0;
+    double4_t Rb[4];
+    double *colp = (cok && col == n) ? R + (size_t)blockIdx.y * strideR + j0 : A + (size_t)(cok ? col : min(c0, n - 1)) * lda + j0;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) R[bi][q] = cok ? colp[16 * bi + 4 * q + kr] : 0.0;
+        for (int q = 0; q < 4; ++q) Rb[bi][q] = (cok && 16 * bi + 4 * q + kr < jb) ? colp[16 * bi + 4 * q + kr] : 0.0;
     {
         double v[16];                                              // lane = row: coalesced column reads, 16 in flight
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = (lane <= 16 * wave + j) ? A[(size_t)(j0 + 16 * wave + j) * lda + j0 + lane] : 0.0;
+        for (int j = 0; j < 16; ++j) v[j] = (lane <= 16 * wave + j && 16 * wave + j < jb) ? A[(size_t)(j0 + 16 * wave + j) * lda + j0 + lane] : 0.0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) U[lane * PLD + 16 * wave + j] = v[j];
         for (int e = tid; e < 1024; e += 256) Yt[(e >> 4) * TLD + (e & 15)] = dinv[e];
@@ -95,20 +97,20 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int
         double4_t X = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k0 = 0; k0 < 16; k0 += 4)
-            X = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(16 * bi + l15) * TLD + k0 + kr], R[bi][k0 >> 2], X, 0, 0, 0);
-        R[bi] = X;
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[(16 * bi + l15) * TLD + k0 + kr], Rb[bi][k0 >> 2], X, 0, 0, 0);
+        Rb[bi] = X;
 #pragma unroll
         for (int bj = bi + 1; bj < 4; ++bj)
 #pragma unroll
             for (int k0 = 0; k0 < 16; k0 += 4)
-                R[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(16 * bi + k0 + kr) * PLD + 16 * bj + l15], X[k0 >> 2], R[bj], 0, 0, 0);
+                Rb[bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-U[(16 * bi + k0 + kr) * PLD + 16 * bj + l15], X[k0 >> 2], Rb[bj], 0, 0, 0);
     }
     if (cok) {
-        double *outp = A + (size_t)col * lda + j0;
 #pragma unroll
         for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) outp[16 * bi + 4 * q + kr] = R[bi][q];
+            for (int q = 0; q < 4; ++q)
+                if (16 * bi + 4 * q + kr < jb) colp[16 * bi + 4 * q + kr] = Rb[bi][q];
     }
 }
 
@@ -127,6 +129,8 @@ struct CholUpdArgs {
     size_t strideA;
     const int *active;
     double *dinv; size_t stride_dinv; int *info; int j0;
+    double *R; size_t strideR;     // optional right-hand side riding along as column N of the trailing block:
+    int k0g, r0g;                  //   its entries beside P start at R[k0g], those beside C at R[r0g]
 };
 constexpr int UKC = 16, ULD = UKC + 2;
 // linear id -> tile (tm <= tn) of the upper triangle, column by column
@@ -145,13 +149,19 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
     const int b = blockIdx.y;
     if (g.active && !g.active[b]) return;
+    const int T = (g.N + CB - 1) / CB, tri = T * (T + 1) / 2;
     int tile_m, tile_n;
-    upper_tile(blockIdx.x, &tile_m, &tile_n);
+    if ((int)blockIdx.x < tri) upper_tile(blockIdx.x, &tile_m, &tile_n);
+    else { tile_n = T; tile_m = (int)blockIdx.x - tri; }           // the right-hand side in a tile column of its own
     const int m0 = tile_m * CB, n0 = tile_n * CB;
     const double *P = g.P + (size_t)b * g.strideA;
     double *C = g.C + (size_t)b * g.strideA;
+    double *R = g.R ? g.R + (size_t)b * g.strideR : nullptr;
+    const int NC = g.N + (R ? 1 : 0);                              // columns: the trailing block and the right-hand side
+    auto pcol = [&](int c) -> const double * { return c == g.N ? R + g.k0g : P + (size_t)c * g.lda; };
+    auto ccol = [&](int c) -> double * { return c == g.N ? R + g.r0g : C + (size_t)c * g.lda; };
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
-    const bool diag = m0 == n0;
+    const bool diag = m0 == n0 && (!R || n0 + CB <= g.N);      // one operand block serves both sides (not when the right-hand side is among the tile's columns)
     // old values of the tile, in the accumulator layout: [i][j][r] <-> row m0+wm+16i+l15, column n0+wn+16j+kr+4r
     double cold[2][2][4];
 #pragma unroll
@@ -160,8 +170,8 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = min(m0 + wm + 16 * i + l15, g.N - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, g.N - 1);
-                cold[i][j][r] = C[(size_t)n * g.lda + m];
+                const int m = min(m0 + wm + 16 * i + l15, g.N - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, NC - 1);
+                cold[i][j][r] = ccol(n)[m];
             }
     double4_t acc[2][2];
 #pragma unroll
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const double *Bn = diag ? Pm : Pn;
-    if (blockIdx.x == 0 && g.K <= CB) {
+    if (blockIdx.x == 0 && g.K <= CB && diag) {
         // tile (0, 0) heads the chain of diagonal blocks: its K x 64 operand in one trip through memory
         // (lane = row, a wave fetches whole columns), then the products straight through
         double ra[16];
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
         for (int e = 0; e < 4; ++e) {
             const int c = (tid >> 4) + 16 * e, kk = tid & 15;
             ra[e] = P[(size_t)min(m0 + c, g.N - 1) * g.lda + k0 + kk];
-            if (!diag) rb[e] = P[(size_t)min(n0 + c, g.N - 1) * g.lda + k0 + kk];
+            if (!diag) rb[e] = pcol(min(n0 + c, NC - 1))[k0 + kk];
         }
         if (k0 > 0) __syncthreads();
 #pragma unroll
@@ -232,6 +242,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
                 for (int r = 0; r < 4; ++r) {
                     const int m = wm + 16 * i + l15, n = wn + 16 * j + kr + 4 * r;
                     U[m * PLD + n] = (m <= n && n < jb) ? cold[i][j][r] - acc[i][j][r] : (m == n ? 1.0 : 0.0);
+                    if (R && n == g.N && m < g.N) R[g.r0g + m] = cold[i][j][r] - acc[i][j][r];    // a trailing block narrower than the tile
                 }
         __syncthreads();
         if (wave == 0) potf2_lds(U, invd, jb, g.j0, g.info + b);
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + 16 * i + l15, n = n0 + wn + 16 * j + kr + 4 * r;
-                if (m < g.N && n < g.N) C[(size_t)n * g.lda + m] = cold[i][j][r] - acc[i][j][r];
+                if (m < g.N && n < NC) ccol(n)[m] = cold[i][j][r] - acc[i][j][r];
             }
 }
 
@@ -276,24 +287,28 @@ __global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA
 // their strict lower triangle).  zero_lower = false leaves the strict lower triangle as it is (a caller
 // that only ever reads the upper triangle of the factor saves the pass).
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower)
+                                   bool zero_lower, double *rhs, size_t stride_rhs)
 {
     hipStream_t s = ctx->stream;
     VSLAM_TRY(potf_dinv_reserve(ctx, batch));
     double *dinv = ctx->potf_dinv;
+    const int extra = rhs ? 1 : 0;                    // the right-hand side rides along as column n
     bool factored = false;                            // the diagonal block of this step was factored by the previous update
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
         if (!factored) hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(256), 0, s, A, lda, j0, jb, info, strideA, active, dinv, (size_t)1024);
         const int rest = n - j0 - jb;
-        if (rest <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, dinv, (size_t)1024);
+        if (rest + extra <= 0) break;
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, dinv, (size_t)1024,
+                           rhs, stride_rhs);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
+        if (rest <= 0) break;
         CholUpdArgs g;                                // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
         g.P = A + (size_t)(j0 + jb) * lda + j0; g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.N = rest; g.K = jb; g.lda = lda;
         g.strideA = strideA; g.active = active; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
-        const int T = (rest + CB - 1) / CB;
-        hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2, batch), dim3(256), 0, s, g);
+        g.R = rhs; g.strideR = stride_rhs; g.k0g = j0; g.r0g = j0 + jb;
+        const int T = (rest + CB - 1) / CB, TC = (rest + extra + CB - 1) / CB;
+        hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2 + (TC > T ? T : 0), batch), dim3(256), 0, s, g);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         factored = true;                              // the update's workgroup for the next diagonal tile factors it as well
     }
@@ -414,9 +429,9 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     auto factor_and_step = [&](double lam) -> vslam_status {
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
         if (lam != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(nb), dim3(256), 0, s, w.U, n, n, lam);
-        VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.t, w.gcur, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, true, w.t, 0));      // t = U^-T g comes with the factor
         ++factorisations;
-        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.gcur, w.t));
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p));
         hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, -1.0, w.p, 0.0, (const double *)nullptr, w.p, n);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
@@ -506,21 +521,24 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
 
 // Test hook (not part of the public header): in-place upper Cholesky factors of `batch` symmetric n x n matrices held
 // one after the other on the host (column-major, ld n; only the upper triangles are read); info[b] = 0 or the
-// 1-based column of the first non-positive pivot.
-extern "C" vslam_status vslam_debug_potrf(vslam_ctx *ctx, double *A, int n, int batch, int *info)
+// 1-based column of the first non-positive pivot.  rhs (optional, [batch][n]): replaced by U^-T rhs.
+extern "C" vslam_status vslam_debug_potrf(vslam_ctx *ctx, double *A, int n, int batch, int *info, double *rhs)
 {
     using namespace vslam;
     if (!ctx || !A || !info || n < 1 || batch < 1) return VSLAM_ERR_ARG;
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t nn = (size_t)n * n, bytes = nn * batch * 8;
-    VSLAM_TRY(ws_reserve(ctx, Arena::pad(bytes) + Arena::pad((size_t)batch * sizeof(int))));
+    const size_t nn = (size_t)n * n, bytes = nn * batch * 8, rbytes = (size_t)n * batch * 8;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(bytes) + Arena::pad((size_t)batch * sizeof(int)) + Arena::pad(rbytes)));
     Arena ar(ctx->ws);
     double *dA = ar.take<double>(nn * batch);
     int *dinfo = ar.take<int>(batch);
+    double *dr = ar.take<double>((size_t)n * batch);
     VSLAM_TRY(h2d(ctx, dA, A, bytes));
+    if (rhs) VSLAM_TRY(h2d(ctx, dr, rhs, rbytes));
     VSLAM_HIP_TRY(ctx, hipMemsetAsync(dinfo, 0, (size_t)batch * sizeof(int), ctx->stream));
-    VSLAM_TRY(potrf_upper_batch_dev(ctx, dA, n, n, nn, batch, dinfo, nullptr));
+    VSLAM_TRY(potrf_upper_batch_dev(ctx, dA, n, n, nn, batch, dinfo, nullptr, true, rhs ? dr : nullptr, (size_t)n));
     VSLAM_TRY(d2h(ctx, A, dA, bytes));
     VSLAM_TRY(d2h(ctx, info, dinfo, (size_t)batch * sizeof(int)));
+    if (rhs) VSLAM_TRY(d2h(ctx, rhs, dr, rbytes));
     return stream_finish(ctx);
 }

@@ -13,6 +13,10 @@
 #include "landmark_math.hpp"
 #include "linalg.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -294,8 +298,8 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)B * 8));
         hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), B), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false));
-        trsv(w.U, true, w.gcur, w.t, 1.0, w.active);
+        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.t, w.gcur, (size_t)n, w.active);
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false, w.t, (size_t)n));   // t = U^-T g comes with the factor
         trsv(w.U, false, w.t, w.p, -1.0, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
@@ -341,7 +345,11 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     VSLAM_TRY(send_mask(act));
     VSLAM_TRY(eval(f));                                                   // src/fmin.hpp:39
     accept();
+    const bool trace = getenv("VSLAM_BANK_TRACE") != nullptr;      // diagnostic: per-iteration wall time, filters taking part, multiplier steps
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now_ms();
     for (int it = 0; it < 50 && any(act); ++it) {
+        int trace_steps = 0, trace_active = (int)std::count_if(act.begin(), act.end(), [](int v) { return v != 0; });
         // ---- trust-region subproblem, src/fmin.cpp:40-131 with l1 > 0 ----
         std::fill(lam.begin(), lam.end(), 0.0);
         VSLAM_TRY(send_mask(act));
@@ -366,6 +374,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                     lam[b] = lam_new;
                 }
             if (!any(m)) break;
+            ++trace_steps;
             VSLAM_TRY(send_mask(m));
             VSLAM_TRY(factor_and_step());
             for (int b = 0; b < B; ++b)
@@ -398,6 +407,12 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         if (any(acc)) {
             VSLAM_TRY(send_mask(acc));
             accept();
+        }
+        if (trace) {
+            const double t = now_ms();
+            std::fprintf(stderr, "bank iteration %d: %d filters, %d multiplier steps, %d accepted, %.2f ms\n", it, trace_active, trace_steps,
+                         (int)std::count_if(acc.begin(), acc.end(), [](int v) { return v != 0; }), t - t_prev);
+            t_prev = t;
         }
     }
     // ---- posterior square roots: S = M^-1 with M M^T = H at the final iterate (see newton.hip) ----
