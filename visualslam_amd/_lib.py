@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
+# VSLAM_HIP_LIB: another build of the same library (diagnostic builds, A/B runs)
+LIB_PATH = os.environ.get("VSLAM_HIP_LIB") or os.path.join(_HERE, "libvslam_hip.so")
 
 
 class VslamError(RuntimeError):

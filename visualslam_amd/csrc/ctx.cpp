@@ -103,9 +103,20 @@ vslam_status stream_sync(vslam_ctx *ctx)
     return VSLAM_OK;
 }
 
+// Transfers of this size and more go between device memory and the caller's buffer directly: the runtime moves
+// pageable memory in pipelined pieces, which beats one pass through the staging arena plus one large host copy
+// (and keeps the arena small).  The call returns when the transfer is complete.
+constexpr size_t DIRECT_COPY_BYTES = (size_t)8 << 20;
+
 vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height)
 {
     if (width == 0 || height == 0) return VSLAM_OK;
+    if (width * height >= DIRECT_COPY_BYTES) {
+        if ((spitch == width && dpitch == width) || height == 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, width * height, hipMemcpyHostToDevice, ctx->stream));
+        else VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dst_dev, dpitch, src_host, spitch, width, height, hipMemcpyHostToDevice, ctx->stream));
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // the caller's buffer may change as soon as this returns
+        return VSLAM_OK;
+    }
     char *stage;
     VSLAM_TRY(pinned_take(ctx, width * height, &stage));
     const char *src = static_cast<const char *>(src_host);
@@ -119,6 +130,13 @@ vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *sr
 vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height)
 {
     if (width == 0 || height == 0) return VSLAM_OK;
+    if (width * height >= DIRECT_COPY_BYTES) {
+        // ordered behind everything queued so far; complete on return (a failed call later on cannot leave it pending)
+        if ((spitch == width && dpitch == width) || height == 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, width * height, hipMemcpyDeviceToHost, ctx->stream));
+        else VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(dst_host, dpitch, src_dev, spitch, width, height, hipMemcpyDeviceToHost, ctx->stream));
+        VSLAM_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return VSLAM_OK;
+    }
     char *stage;
     VSLAM_TRY(pinned_take(ctx, width * height, &stage));
     if (spitch == width || height == 1) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(stage, src_dev, width * height, hipMemcpyDeviceToHost, ctx->stream));
