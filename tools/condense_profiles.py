@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("VSLAM_PROFILES_DST") or os.path.join(ROOT, "profiles")   # on the GPU box: a directory under gpurun_out/
 
 
 def kernel_stats(db_path, csv_path):

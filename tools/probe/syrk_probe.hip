@@ -100,6 +100,83 @@ __global__ __launch_bounds__(256, WGS) void syrk_probe(const double *P, double *
             }
 }
 
+// as syrk_probe<16, true, true, true> with the next chunk's loads issued before the current chunk's products
+template <int WGS>
+__global__ __launch_bounds__(256, WGS) void syrk_probe_prefetch(const double *P, double *C, int N, int K, int lda)
+{
+    constexpr int KC = 16, SLD = KC + 2;
+    __shared__ __align__(16) double Ps[2][2 * CB * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
+    int tile_m, tile_n;
+    tri_tile(blockIdx.x, &tile_m, &tile_n);
+    const int m0 = tile_m * CB, n0 = tile_n * CB;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const bool diag = m0 == n0;
+    double cold[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(m0 + wm + 16 * i + l15, N - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, N - 1);
+                cold[i][j][r] = C[(size_t)n * lda + m];
+            }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid >> 4) + 16 * e, kk = tid & 15;
+            ra[e] = P[(size_t)min(m0 + c, N - 1) * lda + k0 + kk];
+            if (!diag) rb[e] = P[(size_t)min(n0 + c, N - 1) * lda + k0 + kk];
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (tid >> 4) + 16 * e, kk = tid & 15;
+            Ps[buf][c * SLD + kk] = ra[e];
+            if (!diag) Ps[buf][CB * SLD + c * SLD + kk] = rb[e];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += KC, buf ^= 1) {
+        if (k0 + KC < K) fetch(k0 + KC);
+        const double *Pm = Ps[buf], *Bn = diag ? Ps[buf] : Ps[buf] + CB * SLD;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double am[2], bn[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) am[i] = Pm[(wm + 16 * i + l15) * SLD + kk + kr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bn[j] = Bn[(wn + 16 * j + l15) * SLD + kk + kr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+        if (k0 + KC < K) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + l15, n = n0 + wn + 16 * j + kr + 4 * r;
+                if (m < N && n < N) C[(size_t)n * lda + m] = cold[i][j][r] - acc[i][j][r];
+            }
+}
+
 template <typename F>
 static float time_it(F f, int reps)
 {
@@ -146,5 +223,14 @@ int main(int argc, char **argv)
     RUN("KC=32 all, 4 WG/CU, xcd runs", 32, true, true, true, 4, 1);
     RUN("KC=32 products only", 32, false, false, true, 4, 0);
     RUN("KC=16 all, 4 WG/CU", 16, true, true, true, 4, 0);
+    RUN("KC=16 all, 5 WG/CU", 16, true, true, true, 5, 0);
+    RUN("KC=16 all, 6 WG/CU", 16, true, true, true, 6, 0);
+#define RUNP(name, w) do { \
+        float us = time_it([&] { hipLaunchKernelGGL((syrk_probe_prefetch<w>), dim3(tiles), dim3(256), 0, 0, P, C, N, K, lda); }, 20); \
+        CK(hipGetLastError()); \
+        printf("%-44s %8.1f us  %6.1f TFLOP/s\n", name, us, flops / us * 1e-6); } while (0)
+    RUNP("KC=16 prefetch + two LDS buffers, 3 WG/CU", 3);
+    RUNP("KC=16 prefetch + two LDS buffers, 4 WG/CU", 4);
+    RUNP("KC=16 prefetch + two LDS buffers, 5 WG/CU", 5);
     return 0;
 }

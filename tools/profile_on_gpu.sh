@@ -19,5 +19,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/qr" -o qr -- python3
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA -d "$OUT/qr_mfma" -o mfma -- python3 "$R/tools/qr_bench.py" 6012 6012 1 > "$OUT/qr_mfma.log" 2>&1 || echo "mfma counter pass failed (counter names may differ)" > "$OUT/qr_mfma.failed"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_affine" -o bank_affine -- python3 "$R/tools/run_bank_affine.py" 512 150 3 > "$OUT/bank_affine.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_iekf" -o bank_iekf -- python3 "$R/tools/run_iekf_bank.py" 150 512 --batched > "$OUT/bank_iekf.log" 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/c4" -o c4 -- python3 "$R/tools/run_c4.py" > "$OUT/c4.log" 2>&1 || echo "config-4 trace failed" > "$OUT/c4.failed"
-ls -R "$OUT" | head -60
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/c4" -o c4 -- python3 "$R/tools/run_update.py" 2000 2 > "$OUT/c4.log" 2>&1 || echo "config-4 trace failed" > "$OUT/c4.failed"
+# the databases are too large to travel back: condensed here, summaries only are kept
+VSLAM_PROFILES_DST="$R/gpurun_out/profiles_out" python3 "$R/tools/condense_profiles.py" "${1:-r02}" || exit 1
+rm -rf "$OUT"/*/
+ls "$R/gpurun_out/profiles_out"
