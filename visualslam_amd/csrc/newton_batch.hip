@@ -162,6 +162,15 @@ __global__ void bk_copy_kernel(double *dst, const double *src, size_t count, con
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[base + i] = src[base + i];
 }
 
+// dst[s] = src[src_of[s]] (count doubles per slot) for every slot s with src_of[s] >= 0
+__global__ void bk_gather_kernel(double *dst, const double *src, size_t count, const int *src_of)
+{
+    const int s = blockIdx.y, from = src_of[s];
+    if (from < 0) return;
+    const size_t to = (size_t)s * count, base = (size_t)from * count, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[to + i] = src[base + i];
+}
+
 // upper triangle of U[b] = that of H[b] + lam[b] I  (n x n, ld n), active instances only; the factorisation and the
 // solves that follow never touch the strict lower triangle.  One column per blockIdx.x step.
 __global__ void bk_shifted_copy_kernel(double *U, const double *H, int n, const double *lam, const int *active)
@@ -227,32 +236,37 @@ __global__ __launch_bounds__(256) void bk_reverse_kernel(const double *A, int n,
     B[o + (size_t)j * n + i] = transposed ? A[o + (size_t)ri * n + rj] : A[o + (size_t)rj * n + ri];
 }
 
+// B filters and Bt - B further slots in which trust-region subproblems of the same filters are solved ahead
+// (iekf_bank_chunk): the slots beyond B own a factor, a current Hessian and the vectors, nothing else.
 struct BankWs {
-    double *Hp, *Hl, *H, *W, *U, *Hcur;                                     // [B][n*n]
-    double *x, *tmp, *gp, *gl, *g, *xcur, *gcur, *p, *t, *q, *xn, *Hpv;     // [B][n]
-    double *vp, *vl, *V, *dots, *lam;                                       // [B] ([B][4] for dots)
-    int *info, *active;                                                     // [B]
+    double *Hp, *Hl, *H, *W;                                                // [B][n*n]
+    double *U, *Hcur;                                                       // [Bt][n*n]
+    double *x, *tmp, *gp, *gl, *g, *xcur, *gcur, *p, *t, *q, *xn, *Hpv;     // [Bt][n]
+    double *vp, *vl, *V, *dots, *lam;                                       // [Bt] ([Bt][4] for dots)
+    int *info, *active, *map;                                               // [Bt]
     void *tws;
 };
 
-size_t bank_ws_bytes(int n, int B)
+size_t bank_ws_bytes(int n, int B, int Bt)
 {
     const size_t nn = (size_t)n * n;
-    return 6 * Arena::pad((size_t)B * nn * 8) + 12 * Arena::pad((size_t)B * n * 8) + 8 * Arena::pad((size_t)B * 4 * 8) + trtri_batch_ws_bytes(n, B);
+    return 4 * Arena::pad((size_t)B * nn * 8) + 2 * Arena::pad((size_t)Bt * nn * 8) + 12 * Arena::pad((size_t)Bt * n * 8) +
+           9 * Arena::pad((size_t)Bt * 4 * 8) + trtri_batch_ws_bytes(n, B);
 }
 
-void bank_carve(void *ws, int n, int B, BankWs *w)
+void bank_carve(void *ws, int n, int B, int Bt, BankWs *w)
 {
     Arena ar(ws);
     const size_t nn = (size_t)n * n;
     w->Hp = ar.take<double>(B * nn); w->Hl = ar.take<double>(B * nn); w->H = ar.take<double>(B * nn);
-    w->W = ar.take<double>(B * nn); w->U = ar.take<double>(B * nn); w->Hcur = ar.take<double>(B * nn);
+    w->W = ar.take<double>(B * nn); w->U = ar.take<double>(Bt * nn); w->Hcur = ar.take<double>(Bt * nn);
     double **v[12] = {&w->x, &w->tmp, &w->gp, &w->gl, &w->g, &w->xcur, &w->gcur, &w->p, &w->t, &w->q, &w->xn, &w->Hpv};
-    for (double **q : v) *q = ar.take<double>((size_t)B * n);
-    w->vp = ar.take<double>(4 * B); w->vl = ar.take<double>(4 * B); w->V = ar.take<double>(4 * B);
-    w->dots = ar.take<double>(4 * B); w->lam = ar.take<double>(4 * B);
-    w->info = reinterpret_cast<int *>(ar.take<double>(4 * B)); w->active = reinterpret_cast<int *>(ar.take<double>(4 * B));
-    ar.take<double>(4 * B);
+    for (double **q : v) *q = ar.take<double>((size_t)Bt * n);
+    w->vp = ar.take<double>(4 * Bt); w->vl = ar.take<double>(4 * Bt); w->V = ar.take<double>(4 * Bt);
+    w->dots = ar.take<double>(4 * Bt); w->lam = ar.take<double>(4 * Bt);
+    w->info = reinterpret_cast<int *>(ar.take<double>(4 * Bt)); w->active = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
+    w->map = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
+    ar.take<double>(4 * Bt);
     w->tws = ar.take<char>(trtri_batch_ws_bytes(n, B));
 }
 
@@ -260,57 +274,88 @@ int grid_for(size_t count) { return (int)std::min<size_t>((count + 1023) / 1024,
 
 }  // namespace
 
+// Slots beyond the B filters of a chunk, for subproblems solved ahead (see iekf_bank_chunk).
+static int bank_extra_slots(int B)
+{
+    if (const char *e = getenv("VSLAM_BANK_SOLVE_AHEAD")) if (atoi(e) == 0) return 0;     // A/B runs
+    return std::min(B, 1024);
+}
+
 // One chunk of B filters, all pointers device except the per-instance result arrays.
+//
+// The filters run in lock step; the host keeps each filter's radius, multiplier, cost and loop state.  Towards
+// the end of an update most filters are finished and the rest go through rejected steps: the cost no longer
+// resolves the step, the radius is quartered (src/fmin.hpp:88-96) and the subproblem is solved again on an
+// unchanged Hessian and gradient -- six to eight dependent factorisations whose kernels leave the chip idle.
+// Those subproblems do not depend on the cost evaluations in between, so they are solved AHEAD: a filter whose
+// step was rejected gets up to SOLVE_AHEAD extra slots beyond the B filters, each with a copy of its Hessian,
+// gradient and iterate and the radius quartered once more, and all of them go through the same launches.  When the
+// filter's next step is rejected as well and its new radius 0.25 |p| equals the radius solved for (to 1e-9
+// relative: it does whenever the solution lay on the boundary, to the 1e-10 of the multiplier iteration), the next
+// subproblem's solution is already there and only the cost evaluation remains.  An accepted step, or a radius that
+// differs, discards what was solved ahead.
 static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma, int n, int B, const double *mu, const double *S,
                                     const double *y, const uint8_t *vis, double *mu_post, double *S_post, int32_t *fmin_code,
                                     int32_t *iters, int32_t *status)
 {
+    constexpr int SOLVE_AHEAD = 6, MAX_ITERATIONS = 50;
     const size_t nn = (size_t)n * n;
     const int L = (n - 12) / 3, nb = (n + 255) / 256;
+    const int Bt = B + bank_extra_slots(B);
     hipStream_t s = ctx->stream;
-    VSLAM_TRY(ws_reserve(ctx, bank_ws_bytes(n, B)));
+    VSLAM_TRY(ws_reserve(ctx, bank_ws_bytes(n, B, Bt)));
     BankWs w;
-    bank_carve(ctx->ws, n, B, &w);
+    bank_carve(ctx->ws, n, B, Bt, &w);
     const size_t trsv_lds = (size_t)(((n + 1) & ~1) + 64 * 65 + 64) * 8;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bk_trsv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
     const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
 
-    std::vector<int> act(B, 1), m(B, 0), acc(B, 0), hinfo(B, 0), ret(B, 1), its(B, 50), stat(B, 0), done(B, 0);
-    std::vector<double> f(B, 0.0), fn(B, 0.0), Delta(B, 1.0), lam(B, 0.0), hd((size_t)4 * B, 0.0), pn(B, 0.0);
+    // per slot (filters 0 .. B-1, then the slots solved ahead)
+    std::vector<int> trs(Bt, 0), m(Bt, 0), hinfo(Bt, 0), map(Bt, -1);
+    std::vector<double> Delta(Bt, 1.0), lam(Bt, 0.0), hd((size_t)4 * Bt, 0.0);
+    // per filter
+    std::vector<int> act(B, 1), acc(B, 0), ret(B, 1), its(B, MAX_ITERATIONS), stat(B, 0), done(B, 0), itb(B, 0), rej(B, 0), cur(B, 0);
+    std::vector<double> f(B, 0.0), fn(B, 0.0);
+    std::vector<std::vector<int>> ahead(B);                     // slots holding the filter's next subproblems, nearest first
 
-    auto trsv = [&](const double *M, bool trans, const double *rhs, double *out, double scale, const int *mask) {
-        hipLaunchKernelGGL(bk_trsv_kernel, dim3(B), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
+    auto trsv = [&](const double *M, bool trans, const double *rhs, double *out, double scale, const int *mask, int count) {
+        hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
     };
-    auto send_mask = [&](const std::vector<int> &h) -> vslam_status { return h2d(ctx, w.active, h.data(), (size_t)B * sizeof(int)); };
+    // a mask over the filters, or over all slots; the device array always holds Bt words
+    auto send_mask = [&](const std::vector<int> &h) -> vslam_status {
+        VSLAM_TRY(h2d(ctx, w.active, h.data(), h.size() * sizeof(int)));
+        if ((int)h.size() < Bt) VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.active + h.size(), 0, (Bt - h.size()) * sizeof(int), s));
+        return VSLAM_OK;
+    };
     auto any = [&](const std::vector<int> &h) { return std::any_of(h.begin(), h.end(), [](int v) { return v != 0; }); };
-    // results of bk_dots_kernel and the factorisation flags of all instances
+    // results of bk_dots_kernel and the factorisation flags of all slots
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
         BkDotArgs d;
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2;
-        hipLaunchKernelGGL(bk_dots_kernel, dim3(B), dim3(BK_T), 0, s, d, n, w.dots, w.active);
+        hipLaunchKernelGGL(bk_dots_kernel, dim3(Bt), dim3(BK_T), 0, s, d, n, w.dots, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)4 * B * 8));
-        VSLAM_TRY(d2h(ctx, hinfo.data(), w.info, (size_t)B * sizeof(int)));
+        VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)4 * Bt * 8));
+        VSLAM_TRY(d2h(ctx, hinfo.data(), w.info, (size_t)Bt * sizeof(int)));
         return stream_sync(ctx);
     };
-    // for the instances of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
+    // for the slots of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&]() -> vslam_status {
-        VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)B * 8));
-        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), B), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
+        VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)Bt * 8));
+        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), Bt), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.t, w.gcur, (size_t)n, w.active);
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false, w.t, (size_t)n));   // t = U^-T g comes with the factor
-        trsv(w.U, false, w.t, w.p, -1.0, w.active);
+        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, Bt), dim3(256), 0, s, w.t, w.gcur, (size_t)n, w.active);
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, Bt, w.info, w.active, /*zero_lower=*/false, w.t, (size_t)n));   // t = U^-T g comes with the factor
+        trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     };
     bool prior_ready = false;
-    // V, g, H of CostJointDensity (src/gaussian.hpp:435-467) at w.x for every instance; V to the host
+    // V, g, H of CostJointDensity (src/gaussian.hpp:435-467) at w.x for every filter of the mask; V to the host
     auto eval = [&](std::vector<double> &V) -> vslam_status {
         const int *a = w.active;
         hipLaunchKernelGGL(bk_sub_kernel, dim3(1, B), dim3(256), 0, s, w.x, mu, w.tmp, (size_t)n, a);
-        trsv(S, true, w.tmp, w.tmp, 1.0, a);                              // z = S^-T (x - mu)
-        trsv(S, false, w.tmp, w.gp, 1.0, a);                              // S^-1 z (negated below)
+        trsv(S, true, w.tmp, w.tmp, 1.0, a, B);                           // z = S^-T (x - mu)
+        trsv(S, false, w.tmp, w.gp, 1.0, a, B);                           // S^-1 z (negated below)
         hipLaunchKernelGGL(bk_log_gaussian_value_kernel, dim3(B), dim3(BK_T), 0, s, w.tmp, S, nn, n, w.vp, w.gp, a);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (!prior_ready) {                                               // the prior Hessian does not depend on x
@@ -329,89 +374,171 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         VSLAM_TRY(d2h(ctx, V.data(), w.V, (size_t)B * 8));
         return stream_sync(ctx);
     };
-    // current iterate := the point just evaluated, for the instances of the mask on the device
+    // current iterate := the point just evaluated, for the filters of the mask on the device
     auto accept = [&]() {
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.xcur, w.x, (size_t)n, w.active);
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.gcur, w.g, (size_t)n, w.active);
         hipLaunchKernelGGL(bk_copy_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.Hcur, w.H, nn, w.active);
     };
-    auto drop_failed = [&](std::vector<int> &mask) {           // a non-positive pivot: the instance leaves the bank
-        for (int b = 0; b < B; ++b)
-            if (hinfo[b] != 0 && !done[b]) { stat[b] = 1; done[b] = 1; act[b] = 0; mask[b] = 0; }
+    // dst[slot] = src[map[slot]] for the slots whose map entry is not negative
+    auto gather = [&](double *dst, const double *src, size_t count, int slots) {
+        hipLaunchKernelGGL(bk_gather_kernel, dim3(grid_for(count), slots), dim3(256), 0, s, dst, src, count, w.map);
+    };
+    auto send_map = [&]() -> vslam_status { return h2d(ctx, w.map, map.data(), (size_t)Bt * sizeof(int)); };
+    // a non-positive pivot: a filter leaves the bank; a slot solved ahead just drops out with everything behind it
+    auto drop_failed = [&](std::vector<int> &mask) {
+        for (int sl = 0; sl < Bt; ++sl) {
+            if (hinfo[sl] == 0 || !trs[sl]) continue;
+            trs[sl] = 0; mask[sl] = 0; m[sl] = 0;
+            if (sl < B) { stat[sl] = 1; done[sl] = 1; act[sl] = 0; ahead[sl].clear(); }
+            else
+                for (int fb = 0; fb < B; ++fb) {
+                    auto &ch = ahead[fb];
+                    const auto itp = std::find(ch.begin(), ch.end(), sl);
+                    if (itp != ch.end()) { for (auto q = itp; q != ch.end(); ++q) { trs[*q] = 0; mask[*q] = 0; m[*q] = 0; } ch.erase(itp, ch.end()); break; }
+                }
+        }
     };
 
-    VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), s));
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)Bt * sizeof(int), s));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.x, mu, (size_t)B * n * 8, hipMemcpyDeviceToDevice, s));
     VSLAM_TRY(send_mask(act));
     VSLAM_TRY(eval(f));                                                   // src/fmin.hpp:39
     accept();
-    const bool trace = getenv("VSLAM_BANK_TRACE") != nullptr;      // diagnostic: per-iteration wall time, filters taking part, multiplier steps
+    const int ahead_pct = getenv("VSLAM_BANK_AHEAD_PCT") ? atoi(getenv("VSLAM_BANK_AHEAD_PCT")) : 50;   // tuning aid
+    const bool trace = getenv("VSLAM_BANK_TRACE") != nullptr;      // diagnostic: per-round wall time, filters taking part, multiplier steps
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now_ms();
-    for (int it = 0; it < 50 && any(act); ++it) {
-        int trace_steps = 0, trace_active = (int)std::count_if(act.begin(), act.end(), [](int v) { return v != 0; });
-        // ---- trust-region subproblem, src/fmin.cpp:40-131 with l1 > 0 ----
+    for (int round = 0; round < MAX_ITERATIONS && any(act); ++round) {
+        int trace_steps = 0, trace_levels = 0, trace_ahead = 0;
+        const int trace_active = (int)std::count(act.begin(), act.end(), 1);
+        // ---- subproblems to solve ahead ----
+        std::fill(trs.begin(), trs.end(), 0);
+        std::fill(map.begin(), map.end(), -1);
+        for (int b = 0; b < B; ++b) { trs[b] = act[b]; ahead[b].clear(); }
+        if (Bt > B) {
+            int nrej = 0, nact = 0;
+            for (int b = 0; b < B; ++b) { nrej += act[b] && rej[b]; nact += act[b]; }
+            // only while the bank is latency bound: filters and subproblems together stay within a fraction of the
+            // bank (beyond it every launch takes longer in proportion and solving ahead costs what it saves)
+            const int room = std::min(Bt - B, B * ahead_pct / 100 - nact);
+            const int levels = (nrej && room > 0) ? std::min(SOLVE_AHEAD, room / nrej) : 0;
+            if (levels >= 1) {
+                int v = B;
+                for (int b = 0; b < B; ++b) {
+                    if (!(act[b] && rej[b])) continue;
+                    double d = Delta[b];
+                    for (int j = 0; j < levels && itb[b] + 1 + j < MAX_ITERATIONS; ++j, ++v) {
+                        d *= 0.25;
+                        Delta[v] = d; trs[v] = 1; map[v] = b; ahead[b].push_back(v);
+                        ++trace_ahead;
+                    }
+                }
+                VSLAM_TRY(send_map());
+                VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info + B, 0, (size_t)(Bt - B) * sizeof(int), s));
+                gather(w.Hcur, w.Hcur, nn, Bt);
+                gather(w.gcur, w.gcur, (size_t)n, Bt);
+                gather(w.xcur, w.xcur, (size_t)n, Bt);
+                VSLAM_HIP_TRY(ctx, hipGetLastError());
+            }
+        }
+        // ---- trust-region subproblems, src/fmin.cpp:40-131 with l1 > 0 ----
         std::fill(lam.begin(), lam.end(), 0.0);
-        VSLAM_TRY(send_mask(act));
+        VSLAM_TRY(send_mask(trs));
         VSLAM_TRY(factor_and_step());
         VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
-        drop_failed(act);
-        for (int b = 0; b < B; ++b) m[b] = act[b] && std::sqrt(hd[(size_t)4 * b]) > Delta[b];
+        {
+            std::vector<int> scratch(Bt, 0);
+            drop_failed(scratch);
+        }
+        for (int sl = 0; sl < Bt; ++sl) m[sl] = trs[sl] && std::sqrt(hd[(size_t)4 * sl]) > Delta[sl];
         for (int kk = 0; kk < 20 && any(m); ++kk) {
             VSLAM_TRY(send_mask(m));
-            trsv(w.U, true, w.p, w.q, 1.0, w.active);
+            trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt);
             VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
             drop_failed(m);
-            std::vector<int> stop(B, 0);
-            for (int b = 0; b < B; ++b)
-                if (m[b]) {
-                    const double ppn = std::sqrt(hd[(size_t)4 * b]), dpp = hd[(size_t)4 * b + 1];
-                    const double ff = 1 / Delta[b] - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);
-                    const double lam_new = std::max(0.0, lam[b] - ff / gg);
+            std::vector<int> stop(Bt, 0);
+            for (int sl = 0; sl < Bt; ++sl)
+                if (m[sl]) {
+                    const double ppn = std::sqrt(hd[(size_t)4 * sl]), dpp = hd[(size_t)4 * sl + 1];
+                    const double ff = 1 / Delta[sl] - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);
+                    const double lam_new = std::max(0.0, lam[sl] - ff / gg);
                     // see trs_multiplier_settled() in linalg.hpp
-                    stop[b] = std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta[b]);
-                    if (lam_new == lam[b]) { stop[b] = 1; m[b] = 0; }       // same multiplier: nothing to refactor
-                    lam[b] = lam_new;
+                    stop[sl] = std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta[sl]);
+                    if (lam_new == lam[sl]) { stop[sl] = 1; m[sl] = 0; }    // same multiplier: nothing to refactor
+                    lam[sl] = lam_new;
                 }
             if (!any(m)) break;
             ++trace_steps;
             VSLAM_TRY(send_mask(m));
             VSLAM_TRY(factor_and_step());
-            for (int b = 0; b < B; ++b)
-                if (stop[b]) m[b] = 0;
+            for (int sl = 0; sl < Bt; ++sl)
+                if (stop[sl]) m[sl] = 0;
         }
-        // ---- src/fmin.hpp:54-105 ----
-        VSLAM_TRY(send_mask(act));
+        // ---- src/fmin.hpp:54-105: predicted decrease and the trial point of every slot ----
+        VSLAM_TRY(send_mask(trs));
         GemmDesc gv;                                   // Hpv = Hcur * p
         gv.M = n; gv.N = 1; gv.K = n; gv.transA = false; gv.transB = false;
-        gv.A = w.Hcur; gv.lda = n; gv.strideA = nn; gv.B = w.p; gv.ldb = n; gv.strideB = n; gv.C = w.Hpv; gv.ldc = n; gv.strideC = n; gv.batch = B; gv.active = w.active;
+        gv.A = w.Hcur; gv.lda = n; gv.strideA = nn; gv.B = w.p; gv.ldb = n; gv.strideB = n; gv.C = w.Hpv; gv.ldc = n; gv.strideC = n; gv.batch = Bt; gv.active = w.active;
         VSLAM_TRY(gemm_f64(ctx, gv));
-        hipLaunchKernelGGL(bk_axpby_kernel, dim3(nb, B), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n, w.active);
+        hipLaunchKernelGGL(bk_axpby_kernel, dim3(nb, Bt), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n, w.active);
         VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hpv, w.p, w.p));
-        drop_failed(act);
+        {
+            std::vector<int> scratch(Bt, 0);
+            drop_failed(scratch);
+        }
+        // ---- the filters' iterations: first on their own subproblem, then, rejected step after rejected step, on
+        //      those solved ahead ----
+        std::vector<int> pend(act);
+        for (int b = 0; b < B; ++b) cur[b] = b;
+        while (any(pend)) {
+            ++trace_levels;
+            for (int b = 0; b < B; ++b)
+                if (pend[b] && std::fabs(-hd[(size_t)4 * cur[b]]) < 2 * eps) {                       // src/fmin.hpp:61-67
+                    ret[b] = 0; its[b] = itb[b]; done[b] = 1; act[b] = 0; pend[b] = 0; ahead[b].clear();
+                }
+            if (!any(pend)) break;
+            std::fill(map.begin(), map.end(), -1);
+            for (int b = 0; b < B; ++b)
+                if (pend[b]) map[b] = cur[b];
+            VSLAM_TRY(send_map());
+            gather(w.x, w.xn, (size_t)n, B);
+            VSLAM_TRY(send_mask(pend));
+            VSLAM_TRY(eval(fn));
+            std::vector<int> next(B, 0);
+            for (int b = 0; b < B; ++b) {
+                acc[b] = 0;
+                if (!pend[b]) continue;
+                const int sl = cur[b];
+                const double pg = hd[(size_t)4 * sl], pHp = hd[(size_t)4 * sl + 1], pnb = std::sqrt(hd[(size_t)4 * sl + 2]);
+                const double dm = -pg - 0.5 * pHp, rho = (f[b] - fn[b]) / dm;
+                double Dn = Delta[sl];
+                if (rho < 0.1) Dn = 0.25 * pnb;
+                else if (rho > 0.75 && pnb > 0.8 * Delta[sl]) Dn = 2.0 * Delta[sl];
+                Delta[b] = Dn;
+                ++itb[b];
+                if (rho >= 0.001) { f[b] = fn[b]; acc[b] = 1; rej[b] = 0; ahead[b].clear(); }
+                else {
+                    rej[b] = 1;
+                    if (!ahead[b].empty() && itb[b] < MAX_ITERATIONS && std::fabs(Delta[ahead[b].front()] - Dn) <= 1e-9 * Dn) {
+                        cur[b] = ahead[b].front();
+                        ahead[b].erase(ahead[b].begin());
+                        next[b] = 1;
+                    } else ahead[b].clear();
+                }
+            }
+            if (any(acc)) {
+                VSLAM_TRY(send_mask(acc));
+                accept();
+            }
+            pend.swap(next);
+        }
         for (int b = 0; b < B; ++b)
-            if (act[b] && std::fabs(-hd[(size_t)4 * b]) < 2 * eps) { ret[b] = 0; its[b] = it; done[b] = 1; act[b] = 0; }   // src/fmin.hpp:61-67
-        if (!any(act)) break;
-        VSLAM_TRY(send_mask(act));
-        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.x, w.xn, (size_t)n, w.active);
-        VSLAM_TRY(eval(fn));
-        for (int b = 0; b < B; ++b) {
-            acc[b] = 0;
-            if (!act[b]) continue;
-            const double pg = hd[(size_t)4 * b], pHp = hd[(size_t)4 * b + 1], pnb = std::sqrt(hd[(size_t)4 * b + 2]);
-            const double dm = -pg - 0.5 * pHp, rho = (f[b] - fn[b]) / dm;
-            if (rho < 0.1) Delta[b] = 0.25 * pnb;
-            else if (rho > 0.75 && pnb > 0.8 * Delta[b]) Delta[b] = 2.0 * Delta[b];
-            if (rho >= 0.001) { f[b] = fn[b]; acc[b] = 1; }
-        }
-        if (any(acc)) {
-            VSLAM_TRY(send_mask(acc));
-            accept();
-        }
+            if (act[b] && itb[b] >= MAX_ITERATIONS) { act[b] = 0; done[b] = 1; }                    // ret stays 1, its stays at the limit
         if (trace) {
             const double t = now_ms();
-            std::fprintf(stderr, "bank iteration %d: %d filters, %d multiplier steps, %d accepted, %.2f ms\n", it, trace_active, trace_steps,
-                         (int)std::count_if(acc.begin(), acc.end(), [](int v) { return v != 0; }), t - t_prev);
+            std::fprintf(stderr, "bank round %d: %d filters + %d subproblems solved ahead, %d multiplier steps, %d evaluation passes, %.2f ms\n", round,
+                         trace_active, trace_ahead, trace_steps, trace_levels, t - t_prev);
             t_prev = t;
         }
     }
@@ -421,6 +548,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     VSLAM_TRY(send_mask(ok));
     hipLaunchKernelGGL(bk_reverse_kernel, dim3(nb, n, B), dim3(256), 0, s, w.Hcur, n, w.U, 0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), s));
     VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active));
     hipLaunchKernelGGL(bk_reverse_kernel, dim3(nb, n, B), dim3(256), 0, s, w.U, n, w.Hl, 1);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
@@ -456,7 +584,7 @@ extern "C" vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, 
     const size_t nn = (size_t)n * n;
     const int L = (n - 12) / 3;
     // instances per pass: the work matrices of one pass stay under 16 GiB
-    size_t chunk = ((size_t)16 << 30) / (7 * nn * 8);
+    size_t chunk = ((size_t)16 << 30) / (9 * nn * 8);
     chunk = std::max<size_t>(1, std::min<size_t>(chunk, 16384));
     for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
         const int B = std::min<int>((int)chunk, batch - b0);
