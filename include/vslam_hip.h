@@ -212,7 +212,12 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
  * 1e-10 relative, not bit for bit: the multiplier iteration of the trust-region subproblem also stops once
  * |p| matches the radius to 1e-10 relative (with a collapsed trust region the reference's absolute test
  * |1/Delta - 1/|p|| < sqrt(eps) asks for more digits than the quantity has), and the accept / radius tests
- * on rho are discontinuous, so a last-bit difference can in principle change a decision.
+ * on rho are discontinuous, so a last-bit difference can in principle change a decision.  The same holds for
+ * the subproblems the bank solves ahead: a filter whose step was rejected has its next subproblems (radius
+ * quartered again and again, Hessian and gradient unchanged) solved in spare slots beside the running ones,
+ * and a solution is used when the radius the reference would set, 0.25 |p|, equals the one solved for to 1e-9
+ * relative (VSLAM_BANK_SOLVE_AHEAD=0 in the environment switches this off; the work space grows by up to two
+ * n x n matrices per filter for the spare slots).
  * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = its Hessian was not positive definite
  * at some iterate: its outputs are meaningless and the caller redoes that filter with
  * vslam_measurement_update_iekf.  Returns after the results are complete. */

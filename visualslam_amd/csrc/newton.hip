@@ -7,7 +7,8 @@
 // same quantities follow from Cholesky factors H + lam I = U^T U:
 //     p = -U^-1 U^-T g,      p^T (H + lam I)^-1 p = |U^-T p|^2,
 // so the iteration below produces the reference's sequence of lam (start 0, lower clamp 0, same
-// update and stopping rule) without an eigensolver; everything stays in HBM and only a handful of
+// update; it also stops once |p| matches Delta to 1e-10 relative, see trs_multiplier_settled in
+// linalg.hpp) without an eigensolver; everything stays in HBM and only a handful of
 // scalars cross PCIe per iteration.  An iterate whose Hessian is not positive definite is handed
 // back to the caller, which takes the eigenvalue route for it.
 //
