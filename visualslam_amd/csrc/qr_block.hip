@@ -247,6 +247,79 @@ __device__ __forceinline__ void qb_trsm_row(double (&x)[32], int oR, int oinvd)
     }
 }
 
+// Neighbouring lanes 2q, 2q+1 work as a pair: value of the pair's lane ODD for both / the partner's value (DPP quad_perm).
+template <int ODD>
+__device__ __forceinline__ double qb_pair_bcast(double v)
+{
+    constexpr int ctrl = ODD ? 0xF5 : 0xA0;                   // quad_perm [1,1,3,3] / [0,0,2,2]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qb_pair_swap(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// The same row solve shared by a pair of lanes: lane h of the pair holds the entries j = 2 t + h.  Every entry goes
+// through the operations of qb_trsm_row in the same order (same bits); the pair halves the multiply-adds and the
+// broadcast reads per lane, the finished entry x_k crosses the pair by DPP.
+__device__ __forceinline__ void qb_trsm_row2(double (&x)[16], int h, int oR, int oinvd)
+{
+    const double *R = qb_lds + oR + h, *invd = qb_lds + oinvd;
+    double cur[16];                                             // row k of R at this lane's columns; refilled with row k+1 as it is used up
+#pragma unroll
+    for (int t = 0; t < 16; ++t) cur[t] = R[2 * t];
+    double inv = invd[0];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int tk = k >> 1;
+        const double own = x[tk] * inv;
+        const double xk = (k & 1) ? qb_pair_bcast<1>(own) : qb_pair_bcast<0>(own);
+        x[tk] = (h == (k & 1)) ? xk : x[tk];
+        if (k + 1 < 32) inv = invd[k + 1];
+        // four of this lane's columns at a time: apply row k, then refill those registers with row k+1
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            if (4 * c4 + 3 >= tk) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = 4 * c4 + u;
+                    if (t > tk) { x[t] -= cur[t] * xk; QB_PIN(x[t]); }
+                    else if (t == tk && (k & 1) == 0) { x[t] -= (h ? cur[t] : 0.0) * xk; QB_PIN(x[t]); }     // j = k + 1 belongs to the odd lane
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = 4 * c4 + u;
+                    if (k + 1 < 32 && t >= ((k + 1) >> 1)) cur[t] = R[(k + 1) * QB_LDM + 2 * t];
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+// Rows first_row + (t >> 1) + (nthreads / 2) * pass < row_end (except those in [skip_lo, skip_hi)) of the nb-column matrix
+// at qb_lds[oB + i * rs + j * cs]:  row <- row R^-1, two lanes per row; t = this thread's number among the nthreads
+// (a multiple of 64) that share the work.
+__device__ QB_NOINLINE void qb_trsm_rows2(int oB, int rs, int cs, int first_row, int row_end, int nthreads, int t, int skip_lo, int skip_hi,
+                                          int oR, int oinvd, int nb)
+{
+    const int h = t & 1;
+    for (int i = first_row + (t >> 1); i < row_end; i += nthreads >> 1) {
+        if (i >= skip_lo && i < skip_hi) continue;
+        double *row = qb_lds + oB + (size_t)i * rs;
+        double xr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = (2 * q + h < nb) ? row[(size_t)(2 * q + h) * cs] : 0.0;
+        qb_trsm_row2(xr, h, oR, oinvd);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (2 * q + h < nb) row[(size_t)(2 * q + h) * cs] = xr[q];
+    }
+}
+
 // One wave: the signed elimination of the reconstruction.  In: Q (Q1_top, LDS), R2 (upper, LDS).
 // Finds S = diag(+-1) and Q - S R2 = Y1 W with Y1 unit lower, W upper (= U R2); Q is overwritten with
 // Y1 (strictly lower part) and W (upper part), invw[k] = 1 / W_kk, sgn[k] = S_k.
@@ -345,40 +418,39 @@ __device__ QB_NOINLINE void qb_rr_upper(int oR2, int oR1, int oDst, int cs, int 
 }
 
 // One wave: T^T = -Y1^-1 S U^T with U = W R2^-1 (W = U R2 and Y1 as left by qb_lu_signed in oQ), written to oT
-// as a full 32 x 32 lower-triangular matrix (row-major, zeros elsewhere and beyond nb).  Lane j owns column j of T^T.
+// as a full 32 x 32 lower-triangular matrix (row-major, zeros elsewhere and beyond nb).  The lane pair (2 j, 2 j + 1)
+// owns column j of T^T, lane h of the pair the rows i = 2 t + h.
 __device__ QB_NOINLINE void qb_make_tt(int oQ, int oR2, int oinvd2, int osgn, int oT, int nb)
 {
-    const int lane = threadIdx.x & 63, j = lane & 31;
+    const int lane = threadIdx.x & 63, j = lane >> 1, h = lane & 1;
     const double *Q = qb_lds + oQ, *sgn = qb_lds + osgn;
-    double ur[32];
+    double tt[16];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) ur[i] = (i >= j) ? Q[j * QB_LDM + i] : 0.0;                         // row j of W
-    qb_trsm_row(ur, oR2, oinvd2);                                                                    // row j of U
-    double tt[32];
+    for (int t = 0; t < 16; ++t) tt[t] = (2 * t + h >= j) ? Q[j * QB_LDM + 2 * t + h] : 0.0;          // row j of W
+    qb_trsm_row2(tt, h, oR2, oinvd2);                                                                // row j of U
 #pragma unroll
-    for (int i = 0; i < 32; ++i) tt[i] = (i >= j && i < nb && j < nb) ? -sgn[i] * ur[i] : 0.0;        // -(S U^T)(i, j)
-    // forward substitution with the unit lower Y1, a row of Y1 (broadcast reads) per step, fetched a step ahead
-    double y[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) y[k] = 0.0;
+    for (int t = 0; t < 16; ++t) {
+        const int i = 2 * t + h;
+        tt[t] = (i >= j && i < nb && j < nb) ? -sgn[i] * tt[t] : 0.0;                                 // -(S U^T)(i, j)
+    }
+    // forward substitution with the unit lower Y1: each lane sums over its own rows, the pair adds up
 #pragma unroll
     for (int i = 1; i < 32; ++i) {
-#pragma unroll
-        for (int k = 0; k < i; ++k) y[k] = Q[i * QB_LDM + k];
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k + 1 < i; ++k) {
-            if (k & 1) s1 += y[k] * tt[k];
-            else s0 += y[k] * tt[k];
+        for (int t = 0; 2 * t < i; ++t) {
+            const bool in = 2 * t + h < i;                                                           // only the last term of the odd lane can fall out
+            const double yv = in ? Q[i * QB_LDM + min(2 * t + h, 31)] : 0.0;
+            if (t & 1) s1 += yv * tt[t];
+            else s0 += yv * tt[t];
         }
-        tt[i] = (tt[i] - (s0 + s1)) - y[i - 1] * tt[i - 1];
-        QB_PIN(tt[i]);
+        const double part = s0 + s1, sum = part + qb_pair_swap(part);
+        if (h == (i & 1)) tt[i >> 1] -= sum;
+        QB_PIN(tt[i >> 1]);
         asm volatile("" ::: "memory");
     }
-    if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) qb_lds[oT + i * QB_LDM + j] = tt[i];
-    }
+    for (int t = 0; t < 16; ++t) qb_lds[oT + (2 * t + h) * QB_LDM + j] = tt[t];
 }
 
 // Value of the explicit reflector matrix at local row i, panel column a (block column c0 + a): zero above the
@@ -587,8 +659,10 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
         QB_STAMP(3);
         if (fast) {
             // ---- Q1 = P R1^-1 on the local rows and on the copy of the top rows ----
-            qb_trsm_rows(c0 * ldr, 1, ldr, lo + tid, nr, QB_T, 0, 0, oM0, oinvd1, nb);
-            if (wave == 3) qb_trsm_rows(oM2, QB_LDM, 1, lane, 32, 64, 0, 0, oM0, oinvd1, 32);
+            // few rows per workgroup: two lanes per row on three waves, the copy of the top rows on the fourth
+            if (nr - lo <= 96) { if (wave < 3) qb_trsm_rows2(c0 * ldr, 1, ldr, lo, nr, 192, tid, 0, 0, oM0, oinvd1, nb); }
+            else qb_trsm_rows(c0 * ldr, 1, ldr, lo + tid, nr, QB_T, 0, 0, oM0, oinvd1, nb);
+            if (wave == 3) qb_trsm_rows2(oM2, QB_LDM, 1, 0, 32, 64, lane, 0, 0, oM0, oinvd1, 32);
             __syncthreads();
             QB_STAMP(4);
             // ---- G2 = Q1^T Q1: how orthonormal Q1 came out ----
@@ -632,7 +706,8 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
         }
         if (fast) {
             // ---- reflectors below the top rows: Y2 = Q1 (U R2)^-1; wave 2: T^T; wave 3 of the owner: finish the top rows ----
-            qb_trsm_rows(c0 * ldr, 1, ldr, lo + tid, nr, QB_T, c0 - rb, c0 + nb - rb, oM2, oinvw, nb);
+            if (nr - lo <= 64) { if (wave < 2) qb_trsm_rows2(c0 * ldr, 1, ldr, lo, nr, 128, tid, c0 - rb, c0 + nb - rb, oM2, oinvw, nb); }
+            else qb_trsm_rows(c0 * ldr, 1, ldr, lo + tid, nr, QB_T, c0 - rb, c0 + nb - rb, oM2, oinvw, nb);
             if (wave == 2) qb_make_tt(oM2, oM1, oinvd2, osgn, oM0, nb);
             if (wave == 3 && owner)
                 for (int e = lane; e < 1024; e += 64) {
