@@ -320,63 +320,126 @@ __device__ QB_NOINLINE void qb_trsm_rows2(int oB, int rs, int cs, int first_row,
     }
 }
 
-// One wave: the signed elimination of the reconstruction.  In: Q (Q1_top, LDS), R2 (upper, LDS).
-// Finds S = diag(+-1) and Q - S R2 = Y1 W with Y1 unit lower, W upper (= U R2); Q is overwritten with
-// Y1 (strictly lower part) and W (upper part), invw[k] = 1 / W_kk, sgn[k] = S_k.
-// Lanes 0..31 hold the matrix by columns, lanes 32..63 its transpose (by rows): the pivot row lives across
-// the first half, the pivot column across the second, so each goes to LDS with one store and drives the
-// other half's update as broadcast reads -- one FMA per trailing row/column and step for both copies.
-// buf: 128 doubles of LDS.  False when a pivot ratio alpha_k / |x_k| is too close to 0 or to +-1 to be
-// decided here.
-__device__ QB_NOINLINE bool qb_lu_signed(int oQ, int oR2, int oinvw, int osgn, int obuf)
+// value of position R in this lane's row of 16 lanes, for every lane of the row (DPP row_share): a broadcast that
+// stays in vector registers
+template <int R>
+__device__ __forceinline__ double qb_rowshare(double v)
 {
-    double *Q = qb_lds + oQ, *invw = qb_lds + oinvw, *sgn = qb_lds + osgn, *buf = qb_lds + obuf;
-    const double *R2 = qb_lds + oR2;
-    const int lane = threadIdx.x & 63, c = lane >> 5, t = lane & 31;
-    double w[32], r2v[32], pa[32];                              // pa: what step k-1 stored for the other half, in flight during the pivot work
-#pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        w[m] = c ? Q[t * QB_LDM + m] : Q[m * QB_LDM + t];
-        r2v[m] = (!c && m <= t) ? R2[m * QB_LDM + t] : 0.0;
-        pa[m] = 0.0;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + R, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + R, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Step K of the signed elimination of a 16 x 16 block held by columns (lane c of every row of 16 lanes owns column
+// c: a[r] = row r, r2c[r] = R2(r, c) or 0 below the diagonal).
+// Lanes left of the pivot column keep their entries (their multiplicand is zero); the pivot lane's own entries
+// below the diagonal stay unscaled until the end (qb_lu16 multiplies them by the lane's pivot reciprocal, myinv).
+template <int K>
+__device__ __forceinline__ void qb_lu16_step(double (&a)[16], const double (&r2c)[16], int c, int lane, double *invw_o, double *sgn_o, bool &ok, double &myinv)
+{
+    const double e = qb_rowshare<K>(a[K]), rkk = qb_rowshare<K>(r2c[K]);
+    const double s = (e >= 0.0) ? -1.0 : 1.0, ae = fabs(e);
+    ok = ok && (ae > 1e-7 * rkk) && (rkk - ae > 1e-12 * rkk);
+    a[K] -= s * r2c[K];                                         // row K of Q - S R2 (nothing left of the diagonal: R2 is upper triangular)
+    const double inv = rcp_f64(e - s * rkk);
+    if (lane == K) { invw_o[K] = inv; sgn_o[K] = s; }
+    myinv = (c == K) ? inv : myinv;
+    if constexpr (K < 15) {
+        const double akm = (c > K) ? a[K] : 0.0;
+#define QB_LU16_ROW(M) if constexpr ((M) > K) { a[M] -= (qb_rowshare<K>(a[M]) * inv) * akm; QB_PIN(a[M]); }
+        QB_LU16_ROW(1) QB_LU16_ROW(2) QB_LU16_ROW(3) QB_LU16_ROW(4) QB_LU16_ROW(5) QB_LU16_ROW(6) QB_LU16_ROW(7) QB_LU16_ROW(8)
+        QB_LU16_ROW(9) QB_LU16_ROW(10) QB_LU16_ROW(11) QB_LU16_ROW(12) QB_LU16_ROW(13) QB_LU16_ROW(14) QB_LU16_ROW(15)
+#undef QB_LU16_ROW
     }
+}
+
+// One wave: the signed elimination of the 16 x 16 block at (o, o) of Q (LDS) against the same block of R2; multipliers
+// below the diagonal and W on and above it go back to Q, invw / sgn for the 16 pivots.
+__device__ __forceinline__ bool qb_lu16(double *Q, const double *R2, int o, double *invw, double *sgn)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    double a[16], r2c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a[r] = Q[(o + r) * QB_LDM + o + c]; r2c[r] = (r <= c) ? R2[(o + r) * QB_LDM + o + c] : 0.0; }
     bool ok = true;
-    double myinv = 0.0, vprev = 0.0;
+    double myinv = 0.0;
+    qb_lu16_step<0>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<1>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<2>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<3>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<4>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<5>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<6>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<7>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<8>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<9>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<10>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<11>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<12>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<13>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    qb_lu16_step<14>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv); qb_lu16_step<15>(a, r2c, c, lane, invw + o, sgn + o, ok, myinv);
+    if (lane < 16) {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        if (k >= 1) {
-#pragma unroll
-            for (int m = k + 1; m < 32; ++m) pa[m] = buf[((k + 1) & 1) * 64 + (1 - c) * 32 + m];
-        }
-        asm volatile("" ::: "memory");
-        const double e = readlane_f64(w[k], k), rkk = readlane_f64(r2v[k], k);
-        const double s = (e >= 0.0) ? -1.0 : 1.0;
-        const double ae = fabs(e);
-        ok = ok && (ae > 1e-7 * rkk) && (rkk - ae > 1e-12 * rkk);
-        const double inv = rcp_f64(e - s * rkk);
-        const double v = c ? w[k] * inv : w[k] - s * r2v[k];    // first half: W_kt, second half: multiplier of row t
-        buf[(k & 1) * 64 + lane] = v;
-        if (t >= k) w[k] = v;
-        if (lane == k) { invw[k] = inv; sgn[k] = s; myinv = inv; }
-        const double vm = (t > k) ? v : 0.0;
-        if (k >= 1) {
-#pragma unroll
-            for (int m = k + 1; m < 32; ++m) { w[m] -= pa[m] * vprev; QB_PIN(w[m]); }
-        }
-        if (k + 1 < 32) {
-            const double a0 = readlane_f64(v, 32 + k + 1), a1 = readlane_f64(v, k + 1);
-            w[k + 1] -= (c ? a1 : a0) * vm;
-            QB_PIN(w[k + 1]);
-        }
-        vprev = vm;
-        asm volatile("" ::: "memory");
-    }
-    if (c == 0) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) Q[i * QB_LDM + t] = (i > t) ? w[i] * myinv : w[i];
+        for (int r = 0; r < 16; ++r) Q[(o + r) * QB_LDM + o + c] = (r > c) ? a[r] * myinv : a[r];
     }
     return ok;
 }
+
+// The signed elimination of the reconstruction by the whole workgroup, in two steps of 16 pivots.
+// In: Q (Q1_top, LDS), R2 (upper, LDS).  Finds S = diag(+-1) and Q - S R2 = Y1 W with Y1 unit lower, W upper (= U R2);
+// Q is overwritten with Y1 (strictly lower part) and W (upper part), invw[k] = 1 / W_kk, sgn[k] = S_k.
+//   wave 0: the leading 16 x 16 block in registers, the pivot row and the multipliers handed round by DPP row_share;
+//   wave 1: W12 = L11^-1 (Q12 - S1 R2_12), a lane per column;   wave 2: L21 = Q21 W11^-1, a lane per row;
+//   wave 0: Q22 -= L21 W12 on the matrix cores, then the trailing block like the leading one.
+// Every wave of the workgroup calls this (three barriers inside).  *verdict (LDS) = 0 when a pivot ratio
+// alpha_k / |x_k| is too close to 0 or to +-1 to be decided here.
+__device__ QB_NOINLINE void qb_lu_signed_wg(int oQ, int oR2, int oinvw, int osgn, int *verdict)
+{
+    double *Q = qb_lds + oQ, *invw = qb_lds + oinvw, *sgn = qb_lds + osgn;
+    const double *R2 = qb_lds + oR2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, kr = lane >> 4;
+    bool ok = true;
+    if (wave == 0) ok = qb_lu16(Q, R2, 0, invw, sgn);
+    __syncthreads();
+    if (wave == 1) {
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = Q[r * QB_LDM + 16 + c] - sgn[r] * R2[r * QB_LDM + 16 + c];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+#pragma unroll
+            for (int m2 = k + 1; m2 < 16; ++m2) { x[m2] -= Q[m2 * QB_LDM + k] * x[k]; QB_PIN(x[m2]); }
+            asm volatile("" ::: "memory");
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[r * QB_LDM + 16 + c] = x[r];
+        }
+    } else if (wave == 2) {
+        double yv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) yv[k] = Q[(16 + c) * QB_LDM + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            yv[k] *= invw[k];
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) { yv[j] -= Q[k * QB_LDM + j] * yv[k]; QB_PIN(yv[j]); }
+            asm volatile("" ::: "memory");
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Q[(16 + c) * QB_LDM + k] = yv[k];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double4_t t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = Q[(16 + 4 * r + kr) * QB_LDM + 16 + c];
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4)
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(-Q[(16 + c) * QB_LDM + k0 + kr], Q[(k0 + kr) * QB_LDM + 16 + c], t, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Q[(16 + 4 * r + kr) * QB_LDM + 16 + c] = t[r];
+        const bool ok2 = qb_lu16(Q, R2, 16, invw, sgn);
+        if (lane == 0) *verdict = (ok && ok2) ? 1 : 0;
+    }
+    __syncthreads();
+}
+
 
 // Rows i = row_begin, row_begin + row_step, ... < row_end (except those in [skip_lo, skip_hi)) of the nb-column
 // matrix at qb_lds[oB + i * rs + j * cs]:  row <- row R^-1.
@@ -395,27 +458,34 @@ __device__ QB_NOINLINE void qb_trsm_rows(int oB, int rs, int cs, int row_begin, 
     }
 }
 
-// Lanes 0..31 of one wave: the upper triangle of R2 R1 (both upper, zero below the diagonal) to
-// qb_lds[oDst + j * cs + i] for i <= j < nb, lane j owning column j.
+// One wave: the upper triangle of R2 R1 (both upper, zero below the diagonal) to qb_lds[oDst + j * cs + i] for
+// i <= j < nb, on the matrix cores: the three 16 x 16 tiles on and above the diagonal, K = 32 each.
 __device__ QB_NOINLINE void qb_rr_upper(int oR2, int oR1, int oDst, int cs, int nb)
 {
-    const int j = threadIdx.x & 63;
-    if (j >= 32) return;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, kr = lane >> 4;
     const double *R2 = qb_lds + oR2, *R1 = qb_lds + oR1;
-    double r1[32];
+    double4_t t[3];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) r1[k] = R1[k * QB_LDM + j];
-#pragma unroll 1
-    for (int i = 0; i < nb; ++i) {                               // one row of R2 per trip keeps the loads of a trip together
-        double s0 = 0.0, s1 = 0.0;
+    for (int q = 0; q < 3; ++q) t[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            s0 += (k >= i ? R2[i * QB_LDM + k] : 0.0) * r1[k];
-            s1 += (k + 1 >= i ? R2[i * QB_LDM + k + 1] : 0.0) * r1[k + 1];
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+        const double a0 = R2[l15 * QB_LDM + k0 + kr], a1 = R2[(16 + l15) * QB_LDM + k0 + kr];
+        const double b0 = R1[(k0 + kr) * QB_LDM + l15], b1 = R1[(k0 + kr) * QB_LDM + 16 + l15];
+        t[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, t[0], 0, 0, 0);        // tile (0, 0)
+        t[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, t[1], 0, 0, 0);        // tile (0, 1)
+        t[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, t[2], 0, 0, 0);        // tile (1, 1)
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ta = q == 2, tb = q >= 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ta + 4 * r + kr, j = 16 * tb + l15;
+            if (i <= j && j < nb) qb_lds[oDst + (size_t)j * cs + i] = t[q][r];
         }
-        if (i <= j && j < nb) qb_lds[oDst + (size_t)j * cs + i] = s0 + s1;
     }
 }
+
 
 // One wave: T^T = -Y1^-1 S U^T with U = W R2^-1 (W = U R2 and Y1 as left by qb_lu_signed in oQ), written to oT
 // as a full 32 x 32 lower-triangular matrix (row-major, zeros elsewhere and beyond nb).  The lane pair (2 j, 2 j + 1)
@@ -515,7 +585,6 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
     double *tot = red8 + 256, *rc = tot + 32, *wv = rc + 32, *sc = wv + 32;
     int *iflag = reinterpret_cast<int *>(sc + 8);          // [0] dead, [1] verdict of a step
     const int oM0 = (int)(M0 - qb_lds), oM1 = (int)(M1 - qb_lds), oM2 = (int)(M2 - qb_lds);
-    const int ored8 = (int)(red8 - qb_lds);
     const int oinvd1 = (int)(invd1 - qb_lds), oinvd2 = (int)(invd2 - qb_lds), oinvw = (int)(invw - qb_lds), osgn = (int)(sgn - qb_lds);
 
     double *A = a.A + (size_t)b * a.strideA;
@@ -695,12 +764,11 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
             QB_STAMP(8);
         }
         if (fast) {
-            // wave 0: the signed elimination; wave 3 of the owner meanwhile: R2 R1 into the top rows (their Q1 is
+            // the signed elimination (waves 0 to 2); wave 3 of the owner first: R2 R1 into the top rows (their Q1 is
             // no longer needed: M2 holds the copy), signs applied afterwards
             __syncthreads();
-            if (wave == 0) { const bool ok = qb_lu_signed(oM2, oM1, oinvw, osgn, ored8); if (lane == 0) iflag[1] = ok ? 1 : 0; }
             if (wave == 3 && owner) qb_rr_upper(oM1, oM0, c0 * ldr + toploc, ldr, nb);
-            __syncthreads();
+            qb_lu_signed_wg(oM2, oM1, oinvw, osgn, &iflag[1]);
             fast = iflag[1] != 0;
             QB_STAMP(9);
         }
