@@ -840,7 +840,8 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
     qr_carve(ws, rows, cols, batch, &q.w);
     const int kmax = rows < cols ? rows : cols;
     hipStream_t s = ctx->stream;
-    if (q.use_block) VSLAM_HIP_TRY(ctx, hipMemsetAsync(q.w.xflags, 0, (size_t)batch * q.pl.flag_words * 4, s));
+    // the exchange area of qr_block_kernel: its words carry sequence numbers that start at 1 in every factorisation
+    if (q.use_block) VSLAM_HIP_TRY(ctx, hipMemsetAsync(q.w.xbuf, 0, (size_t)batch * q.pl.xbuf_doubles * 8, s));
     if (q.rows_per > 0) {
         const size_t words = (size_t)batch * 3 * CP_GMAX * CP_SLOT * 2;
         VSLAM_HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(q.w.slots), (int)CP_EMPTY32, words, s));

@@ -77,53 +77,81 @@ struct QbArgs {
     int *err;
 };
 
-__device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// An exchanged value is its own ready mark: a double travels as two 64-bit words, each carrying 32 bits of the value and
+// the 32-bit sequence number of the exchange it belongs to (stored and loaded as relaxed 64-bit atomics at agent scope,
+// so a word is never torn).  A reader polls the two words until both carry the number it expects; no separate flag, no
+// drain of the stores before a flag, one trip through memory per hop.  The buffers are zeroed before the first launch of
+// a factorisation and the numbers only grow during it (the first one is 1), so a stale word never matches.
+typedef unsigned long long qb_word;
 struct Xchg {
-    double *part, *mine, *red, *top;
-    unsigned *f1, *f2;
+    qb_word *part;                           // [G][cmax] values: what every workgroup contributes to the current sum
+    qb_word *red;                            // [cmax] values: the sums, each written by the workgroup that owns its slice
+    qb_word *top;                            // [1024] values: the panel's top rows, published by their owner
     int *err;
     int G, g, cmax;
-    unsigned seq;
+    unsigned seq;                            // number of the last exchange entered
     int *dead;                               // LDS word: a wait gave up; every later wait returns at once
     double *scratch;                         // LDS, 256 doubles
 };
 
-// Wave 0: waits until every workgroup's flag has reached seq.
-__device__ __forceinline__ void qb_wait(const Xchg &x, const unsigned *f)
+__device__ __forceinline__ void qb_ll_store(qb_word *item, double v, unsigned seq)
 {
-    const int lane = threadIdx.x & 63;
+    const qb_word bits = (qb_word)__double_as_longlong(v), tag = (qb_word)seq << 32;
+    __hip_atomic_store(item, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(item + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool qb_ll_try(const qb_word *item, unsigned seq, double *v)
+{
+    const qb_word w0 = __hip_atomic_load(item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const qb_word w1 = __hip_atomic_load(item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *v = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+    return (unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq;
+}
+// Polls one value until it belongs to exchange seq.  Bounded: a wait that gives up raises the context's error word
+// and marks the workgroup dead, after which every wait returns at once (with garbage; the call fails as a whole).
+__device__ __forceinline__ double qb_ll_wait(const Xchg &x, const qb_word *item, unsigned seq)
+{
+    double v;
+    if (qb_ll_try(item, seq, &v)) return v;
     unsigned spins = 0;
-    bool dead = *x.dead != 0;
-    for (;;) {
-        bool ok = true;
-        for (int q = lane; q < x.G; q += 64)
-            ok &= (int)(__hip_atomic_load(&f[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - x.seq) >= 0;
-        if (__all(ok) || dead) break;
+    while (*reinterpret_cast<volatile int *>(x.dead) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (qb_ll_try(item, seq, &v)) return v;
         if ((++spins & 63u) == 0) {
             if (spins > QB_SPIN_LIMIT) atomicExch(x.err, 1);
-            if (__hip_atomic_load(x.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { dead = true; if (lane == 0) *x.dead = 1; }
+            if (__hip_atomic_load(x.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) *x.dead = 1;
         }
-        __builtin_amdgcn_s_sleep(1);
     }
+    return v;
 }
 
-// Sums over the workgroups of one matrix the `cnt` words each of them has stored (st_sc1) at x.mine[0..cnt);
-// afterwards x.red[0..cnt) holds the sums (read them with ld_sc1).  Every workgroup gets identical bits.
+// This workgroup's contribution idx to the NEXT exchange (the one the following qb_allreduce enters).  Every workgroup
+// must contribute every index below the count it passes to qb_allreduce.
+__device__ __forceinline__ void qb_put(const Xchg &x, int idx, double v)
+{
+    qb_word *dst = (x.G == 1) ? x.red + 2 * (size_t)idx : x.part + 2 * ((size_t)x.g * x.cmax + idx);
+    qb_ll_store(dst, v, x.seq + 1);
+}
+// Entry idx of the panel's top rows, for the next exchange (owner only) / as published with the last exchange entered.
+__device__ __forceinline__ void qb_put_top(const Xchg &x, int idx, double v) { qb_ll_store(x.top + 2 * (size_t)idx, v, x.seq + 1); }
+__device__ __forceinline__ double qb_top(const Xchg &x, int idx) { return qb_ll_wait(x, x.top + 2 * (size_t)idx, x.seq); }
+// Sum idx of the last exchange entered.  Every workgroup reads every index below the count of that exchange before it
+// contributes to the next one (that is what allows the buffers to be reused without a second set).
+__device__ __forceinline__ double qb_red(const Xchg &x, int idx) { return qb_ll_wait(x, x.red + 2 * (size_t)idx, x.seq); }
+
+// Enters the next exchange: sums over the workgroups of one matrix the `cnt` values each of them has contributed with
+// qb_put; afterwards qb_red(x, idx) returns the sums.  Two hops (reduce-scatter, all-gather): this workgroup adds up its
+// slice of the values in a fixed order, so every workgroup reads identical bits, and publishes it; the gather is the
+// readers' polling.  All threads of the workgroup call this.
 __device__ __forceinline__ void qb_allreduce(Xchg &x, int cnt)
 {
     const int tid = threadIdx.x;
     ++x.seq;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains its payload stores
-    __syncthreads();
-    if (x.G == 1) return;                                        // red aliases mine: own stores, read back after the drain
-    if (tid == 0) __hip_atomic_store(&x.f1[x.g], x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) qb_wait(x, x.f1);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (x.G == 1) return;                                        // the contributions went straight to the sums
     const int per = (((cnt + x.G - 1) / x.G) + 1) & ~1;
     const int e0 = x.g * per, e1 = min(cnt, e0 + per), len = e1 - e0;
+    __syncthreads();                                             // scratch is free again
     if (per <= 128) {
         // several threads per element, each adding a fixed subset of the workgroups in order; the subsets are
         // then added in order: every load of the slice is in flight at once
@@ -133,33 +161,31 @@ __device__ __forceinline__ void qb_allreduce(Xchg &x, int cnt)
             int q = grp;
             for (; q + 7 * ngrp < x.G; q += 8 * ngrp) {
                 double v[8];
+                bool ok[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = ld_sc1(x.part + (size_t)(q + u * ngrp) * x.cmax + e0 + el);
+                for (int u = 0; u < 8; ++u) ok[u] = qb_ll_try(x.part + 2 * ((size_t)(q + u * ngrp) * x.cmax + e0 + el), x.seq, &v[u]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 8; ++u) {
+                    if (!ok[u]) v[u] = qb_ll_wait(x, x.part + 2 * ((size_t)(q + u * ngrp) * x.cmax + e0 + el), x.seq);
+                    s += v[u];
+                }
             }
-            for (; q < x.G; q += ngrp) s += ld_sc1(x.part + (size_t)q * x.cmax + e0 + el);
+            for (; q < x.G; q += ngrp) s += qb_ll_wait(x, x.part + 2 * ((size_t)q * x.cmax + e0 + el), x.seq);
             x.scratch[grp * per + el] = s;
         }
         __syncthreads();
         if (tid < len) {
             double s = 0.0;
             for (int grp2 = 0; grp2 < ngrp; ++grp2) s += x.scratch[grp2 * per + tid];
-            st_sc1(x.red + e0 + tid, s);
+            qb_ll_store(x.red + 2 * (size_t)(e0 + tid), s, x.seq);
         }
     } else {
         for (int e = e0 + tid; e < e1; e += QB_T) {
             double s = 0.0;
-            for (int q = 0; q < x.G; ++q) s += ld_sc1(x.part + (size_t)q * x.cmax + e);
-            st_sc1(x.red + e, s);
+            for (int q = 0; q < x.G; ++q) s += qb_ll_wait(x, x.part + 2 * ((size_t)q * x.cmax + e), x.seq);
+            qb_ll_store(x.red + 2 * (size_t)e, s, x.seq);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&x.f2[x.g], x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) qb_wait(x, x.f2);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ double rsqrt_f64(double d)
@@ -536,7 +562,7 @@ __device__ __forceinline__ double qb_yv(const double *Bk, int ldr, int r0, int c
 // [lo, rows_pad): X = panel columns c0 .. c0+nb (UNIT: as explicit reflectors), Z = columns z0 .. z0+zn.
 template <bool UNIT>
 __device__ __forceinline__ void qb_xtz_tile(const double *Bk, int ldr, int r0, int lo, int rows_pad, int c0, int nb, int z0, int zn,
-                                            double *dst /* [32][32] row-major */)
+                                            const Xchg &x, int dst /* first index of the [32][32] row-major block in the exchange */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ta = wave >> 1, tb = wave & 1;
@@ -569,7 +595,7 @@ __device__ __forceinline__ void qb_xtz_tile(const double *Bk, int ldr, int r0, i
         for (int r = 0; r < 4; ++r) acc[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st_sc1(dst + (16 * ta + 4 * r + kr) * 32 + zc, acc[r]);
+    for (int r = 0; r < 4; ++r) qb_put(x, dst + (16 * ta + 4 * r + kr) * 32 + zc, acc[r]);
 }
 
 __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
@@ -594,11 +620,10 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
     const int rows_pad = (nr + 3) & ~3;
     Xchg x;
     {
-        double *base = a.xbuf + (size_t)b * a.xstride;
-        x.part = base; x.mine = base + (size_t)g * a.cmax;
-        x.red = (a.G == 1) ? x.mine : base + (size_t)a.G * a.cmax;
-        x.top = base + (size_t)(a.G + 1) * a.cmax;
-        x.f1 = a.flags + (size_t)b * a.fstride; x.f2 = x.f1 + a.fstride / 2;
+        qb_word *base = reinterpret_cast<qb_word *>(a.xbuf + (size_t)b * a.xstride);
+        x.part = base;
+        x.red = base + 2 * (size_t)a.G * a.cmax;
+        x.top = base + 2 * (size_t)(a.G + 1) * a.cmax;
         x.err = a.err; x.G = a.G; x.g = g; x.cmax = a.cmax; x.seq = a.seq0; x.dead = iflag; x.scratch = red8;
     }
     if (tid == 0) { iflag[0] = 0; iflag[1] = 0; }
@@ -636,12 +661,12 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                     for (int r = 0; r < 4; ++r) { acc0[r] += acc2[r]; acc1[r] += acc3[r]; }
                 }
                 // chunk ch = zc0 / 32 holds W[a][c] at ch * 1024 + a * 32 + (c - 32 ch)
-                double *dst = x.mine + 1024 * (zc0 >> 5) + (zc0 & 31) + l15;
-                if (zc0 < a.bwc)
+                const int dst = 1024 * (zc0 >> 5) + (zc0 & 31) + l15;
+                if ((zc0 >> 5) < nchunk)                             // every index of the exchange is contributed (zeros beyond the block)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st_sc1(dst + (4 * r + kr) * 32, acc0[r]);
-                    st_sc1(dst + (16 + 4 * r + kr) * 32, acc1[r]);
+                    qb_put(x, dst + (4 * r + kr) * 32, acc0[r]);
+                    qb_put(x, dst + (16 + 4 * r + kr) * 32, acc1[r]);
                 }
             }
             qb_allreduce(x, 1024 * nchunk);
@@ -650,7 +675,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
             for (int ch = 0; ch < nchunk; ++ch) {
                 const int z0 = 32 * ch, zn = min(32, a.bwc - z0);
                 __syncthreads();
-                for (int e = tid; e < 1024; e += QB_T) M1[(e >> 5) * QB_LDM + (e & 31)] = ld_sc1(x.red + 1024 * ch + e);
+                for (int e = tid; e < 1024; e += QB_T) M1[(e >> 5) * QB_LDM + (e & 31)] = qb_red(x, 1024 * ch + e);
                 __syncthreads();
                 double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -705,11 +730,11 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
         bool fast = true;
         QB_STAMP(0);
         // ---- Gram matrix of the panel, the panel's top rows ----
-        qb_xtz_tile<false>(Bk, ldr, rb, lo, rows_pad, c0, nb, c0, nb, x.mine);
+        qb_xtz_tile<false>(Bk, ldr, rb, lo, rows_pad, c0, nb, c0, nb, x, 0);
         if (owner)
             for (int e = tid; e < 1024; e += QB_T) {
                 const int i = e >> 5, j = e & 31;
-                st_sc1(x.top + e, (i < nb && j < nb) ? Bk[(size_t)(c0 + j) * ldr + toploc + i] : 0.0);
+                qb_put_top(x, e, (i < nb && j < nb) ? Bk[(size_t)(c0 + j) * ldr + toploc + i] : 0.0);
             }
         QB_STAMP(1);
         qb_allreduce(x, 1024);
@@ -717,7 +742,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
         for (int e = tid; e < 1024; e += QB_T) {
             const int i = e >> 5, j = e & 31;
             const bool in = i < nb && j < nb;                    // a narrower panel: padded for the 32 x 32 routines
-            const double gv = ld_sc1(x.red + e), tv = ld_sc1(x.top + e);
+            const double gv = qb_red(x, e), tv = qb_top(x, e);
             M0[i * QB_LDM + j] = in ? gv : (i == j ? 1.0 : 0.0);
             M2[i * QB_LDM + j] = in ? tv : (i == j ? 0.5 : 0.0);
         }
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
             __syncthreads();
             QB_STAMP(4);
             // ---- G2 = Q1^T Q1: how orthonormal Q1 came out ----
-            qb_xtz_tile<false>(Bk, ldr, rb, lo, rows_pad, c0, nb, c0, nb, x.mine);
+            qb_xtz_tile<false>(Bk, ldr, rb, lo, rows_pad, c0, nb, c0, nb, x, 0);
             QB_STAMP(5);
             qb_allreduce(x, 1024);
             QB_STAMP(6);
@@ -745,7 +770,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                 bool bad = false;
                 for (int e = tid; e < 1024; e += QB_T) {
                     const int i = e >> 5, j = e & 31;
-                    const double v = ld_sc1(x.red + e);
+                    const double v = qb_red(x, e);
                     const bool in = i < nb && j < nb;
                     M1[i * QB_LDM + j] = in ? v : (i == j ? 1.0 : 0.0);
                     if (in && !(fabs(v - (i == j ? 1.0 : 0.0)) <= 1e-3)) bad = true;
@@ -810,12 +835,12 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                     double s = 0.0;
 #pragma unroll
                     for (int q = 0; q < QB_T / 32; ++q) s += red8[q * 32 + tid];
-                    st_sc1(x.mine + tid, s);
+                    qb_put(x, tid, s);
                     const int li = c0 + c - rb;                               // row c of the panel, if it is here
-                    st_sc1(x.mine + 32 + tid, (li >= 0 && li < nr && tid < nb) ? Bk[(size_t)(c0 + tid) * ldr + li] : 0.0);
+                    qb_put(x, 32 + tid, (li >= 0 && li < nr && tid < nb) ? Bk[(size_t)(c0 + tid) * ldr + li] : 0.0);
                 }
                 qb_allreduce(x, 64);
-                if (tid < 32) { tot[tid] = ld_sc1(x.red + tid); rc[tid] = ld_sc1(x.red + 32 + tid); }
+                if (tid < 32) { tot[tid] = qb_red(x, tid); rc[tid] = qb_red(x, 32 + tid); }
                 __syncthreads();
                 if (tid < 32) {
                     const double alpha = rc[c], tail = tot[c];
@@ -880,13 +905,13 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
             const int nch = (nrest + 31) / 32;
             for (int ch = 0; ch < nch; ++ch) {
                 const int z0 = c0 + nb + 32 * ch, zn = min(32, a.bwc - z0);
-                qb_xtz_tile<true>(Bk, ldr, rb, lo, rows_pad, c0, nb, z0, zn, x.mine + 1024 * ch);
+                qb_xtz_tile<true>(Bk, ldr, rb, lo, rows_pad, c0, nb, z0, zn, x, 1024 * ch);
             }
             qb_allreduce(x, 1024 * nch);
             const int ta = wave >> 1, tb = wave & 1, kr = lane >> 4, l15 = lane & 15;
             for (int ch = 0; ch < nch; ++ch) {
                 const int z0 = c0 + nb + 32 * ch, zn = min(32, a.bwc - z0);
-                for (int e = tid; e < 1024; e += QB_T) M1[(e >> 5) * QB_LDM + (e & 31)] = ld_sc1(x.red + 1024 * ch + e);
+                for (int e = tid; e < 1024; e += QB_T) M1[(e >> 5) * QB_LDM + (e & 31)] = qb_red(x, 1024 * ch + e);
                 __syncthreads();
                 // W <- T^T W
                 double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -970,7 +995,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
         if (p->G > 240) continue;
         p->cmax = bw > 32 ? 32 * bw : 1024;                    // W of one panel of reflectors against every resident column
         p->lds_bytes = lds < ((size_t)96 << 10) ? ((size_t)96 << 10) : lds;     // one workgroup per compute unit
-        p->xbuf_doubles = (size_t)(p->G + 1) * p->cmax + 1024;
+        p->xbuf_doubles = 2 * ((size_t)(p->G + 1) * p->cmax + 1024);      // two words per value: contributions, sums, top rows
         p->flag_words = 2 * ((p->G + 63) & ~63);
         return true;
     }
