@@ -681,6 +681,128 @@ static vslam_status qr_apply_panel(QrJob &q, int j, int jb, const double *Tsrc, 
     return gemm_f64(ctx, g3);
 }
 
+// The two large products of a far update, for a full block of OB = 128 reflectors held explicitly (V: rows x 128,
+// unit diagonal, zeros above it).  Both are bound by how fast operands reach the matrix cores, so they are kept
+// minimal like the trailing update of the Cholesky factorisation (newton.hip): plain indexing, sixteen rows or
+// reflectors at a time through LDS, several workgroups per compute unit.
+typedef double qr_double4 __attribute__((ext_vector_type(4)));
+constexpr int FKC = 16, FLD = FKC + 2;
+
+// Y slab s = V[rows of the slab]^T C[rows of the slab, 64 columns]: a workgroup owns all 128 reflectors against 64
+// columns (32 MFMAs per wave and 16-row chunk against 12 loads per thread), rows split over gridDim.y slabs.
+__global__ __launch_bounds__(256, 3) void qr_far_vtc_kernel(const double *V, int ldv, const double *C, int ldc, int rows, int nc, int kchunk,
+                                                            double *Y /* [slab][nc][OB] */, size_t slab_stride)
+{
+    __shared__ __align__(16) double Vs[OB * FLD], Cs[64 * FLD];        // [reflector / column][row of the chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
+    const int n0 = blockIdx.x * 64, k_begin = blockIdx.y * kchunk, k_end = min(rows, k_begin + kchunk);
+    qr_double4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (qr_double4){0.0, 0.0, 0.0, 0.0};
+    const int kk = tid & 15, cq = tid >> 4;                           // thread: row kk of the chunk, columns cq + 16 e
+    for (int k0 = k_begin; k0 < k_end; k0 += FKC) {
+        double rv[8], rc[4];
+        const bool in = k0 + kk < k_end;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = in ? V[(size_t)(cq + 16 * e) * ldv + k0 + kk] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rc[e] = in ? C[(size_t)min(n0 + cq + 16 * e, nc - 1) * ldc + k0 + kk] : 0.0;
+        if (k0 > k_begin) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vs[(cq + 16 * e) * FLD + kk] = rv[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Cs[(cq + 16 * e) * FLD + kk] = rc[e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < FKC; q += 4) {
+            double am[2], bn[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) am[i] = Vs[(32 * wave + 16 * i + l15) * FLD + q + kr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bn[j] = Cs[(16 * j + l15) * FLD + q + kr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // acc[i][j][r] <-> reflector 32 wave + 16 i + l15, column n0 + 16 j + kr + 4 r
+    double *Ys = Y + (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * j + kr + 4 * r;
+                if (n < nc) Ys[(size_t)n * OB + 32 * wave + 16 * i + l15] = acc[i][j][r];
+            }
+}
+
+// C -= V W for the 128 reflectors: one workgroup per 64 x 64 tile of C, the old tile requested first.
+__global__ __launch_bounds__(256, 4) void qr_far_update_kernel(const double *V, int ldv, const double *W /* [nc][OB] */, double *C, int ldc,
+                                                               int rows, int nc, int tilesM)
+{
+    constexpr int ALD = 64 + 16;                                      // V chunk [reflector][row]: row stride 16 mod 32 doubles
+    __shared__ __align__(16) double Vs[FKC * ALD], Ws[64 * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
+    const int m0 = (blockIdx.x % tilesM) * 64, n0 = (blockIdx.x / tilesM) * 64;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    double cold[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(m0 + wm + 16 * i + l15, rows - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, nc - 1);
+                cold[i][j][r] = C[(size_t)n * ldc + m];
+            }
+    qr_double4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (qr_double4){0.0, 0.0, 0.0, 0.0};
+    const int mrow = min(m0 + lane, rows - 1);
+    const int kk = tid & 15, cq = tid >> 4;
+    for (int k0 = 0; k0 < OB; k0 += FKC) {
+        double rv[4], rw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = V[(size_t)(k0 + wave + 4 * e) * ldv + mrow];            // lane = row: 512 contiguous bytes per reflector
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rw[e] = W[(size_t)min(n0 + cq + 16 * e, nc - 1) * OB + k0 + kk];
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Vs[(wave + 4 * e) * ALD + lane] = rv[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ws[(cq + 16 * e) * FLD + kk] = rw[e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < FKC; q += 4) {
+            double am[2], bn[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) am[i] = Vs[(q + kr) * ALD + wm + 16 * i + l15];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bn[j] = Ws[(wn + 16 * j + l15) * FLD + q + kr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + l15, n = n0 + wn + 16 * j + kr + 4 * r;
+                if (m < rows && n < nc) C[(size_t)n * ldc + m] = cold[i][j][r] - acc[i][j][r];
+            }
+}
+
 // Applies the 128 reflectors of the block held in Vbuf/G/Mo[par] to `nc` columns starting at C
 // (rows j0.. of the matrix) on `stream`:  Y = V^T C (K-slabs) -> W = T^T Y -> C -= V W.
 static vslam_status qr_apply_outer(QrJob &q, int par, int mp0, double *C, int nc, double *W, double *Wpart, hipStream_t stream)
@@ -694,14 +816,33 @@ static vslam_status qr_apply_outer(QrJob &q, int par, int mp0, double *C, int nc
     if (kw < 1) kw = 1;
     const size_t count = (size_t)OB * nc;
     const int ob = q.ob;
-    GemmDesc gw;                                   // Y = V^T C (K-slabs)
-    gw.M = ob; gw.N = nc; gw.K = mp0; gw.transA = true; gw.transB = false;
-    gw.A = q.w.Vbuf[par]; gw.lda = mp0; gw.B = C; gw.ldb = q.lda;
-    gw.C = (kw == 1) ? W : Wpart; gw.ldc = OB; gw.ksplit = kw; gw.strideSplit = count;
-    VSLAM_TRY(gemm_f64_on(ctx, gw, stream));
+    const bool full = ob == OB && !getenv("VSLAM_QR_FAR_GEMM");      // the dedicated kernels take a full block of reflectors
+    if (full) {
+        // 128 x 64 tiles: half as many workgroups per slab as the GEMM's tiling, so more slabs (at most 8: the slab buffer)
+        kw = 768 / ((nc + 63) / 64);
+        if (kw > mp0 / 256) kw = mp0 / 256;
+        if (kw > 8) kw = 8;
+        if (kw < 1) kw = 1;
+        int kchunk = (mp0 + kw - 1) / kw;
+        kchunk = ((kchunk + FKC - 1) / FKC) * FKC;
+        hipLaunchKernelGGL(qr_far_vtc_kernel, dim3((nc + 63) / 64, kw), dim3(256), 0, stream, q.w.Vbuf[par], mp0, C, q.lda, mp0, nc, kchunk,
+                           (kw == 1) ? W : Wpart, count);
+    } else {
+        GemmDesc gw;                                   // Y = V^T C (K-slabs)
+        gw.M = ob; gw.N = nc; gw.K = mp0; gw.transA = true; gw.transB = false;
+        gw.A = q.w.Vbuf[par]; gw.lda = mp0; gw.B = C; gw.ldb = q.lda;
+        gw.C = (kw == 1) ? W : Wpart; gw.ldc = OB; gw.ksplit = kw; gw.strideSplit = count;
+        VSLAM_TRY(gemm_f64_on(ctx, gw, stream));
+    }
     hipLaunchKernelGGL(qr_block_solve_kernel, dim3((nc + SOLVE_CT - 1) / SOLVE_CT, 1), dim3(256), 0, stream,
                        (kw == 1) ? W : Wpart, count, kw, OB, (size_t)0, ob, nc, q.w.G[par], q.w.Mo[par], (size_t)0, W, OB, (size_t)0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
+    if (full) {
+        const int tilesM = (mp0 + 63) / 64;
+        hipLaunchKernelGGL(qr_far_update_kernel, dim3(tilesM * ((nc + 63) / 64)), dim3(256), 0, stream, q.w.Vbuf[par], mp0, W, C, q.lda, mp0, nc, tilesM);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        return VSLAM_OK;
+    }
     GemmDesc gu;                                   // C -= V W
     gu.M = mp0; gu.N = nc; gu.K = ob; gu.transA = false; gu.transB = false; gu.alpha = -1.0; gu.beta = 1.0;
     gu.A = q.w.Vbuf[par]; gu.lda = mp0; gu.B = W; gu.ldb = OB; gu.C = C; gu.ldc = q.lda;
