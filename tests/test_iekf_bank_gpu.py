@@ -216,3 +216,43 @@ def test_bank_larger_than_one_pass(ctx, gcam):
                 assert rel_err(P[b] @ P[b].T, S0.T @ S0) <= 1e-9
     finally:
         ctx.set_trs_solver(api.TRS_CHOLESKY)
+
+
+def test_subproblems_solved_ahead_change_nothing_that_matters(ctx, gcam, monkeypatch):
+    """The bank with and without the subproblems of rejected steps solved ahead (VSLAM_BANK_SOLVE_AHEAD=0): a radius
+    solved ahead is 0.25^k of the filter's radius instead of 0.25 |p| step by step, equal to 1e-9 relative where it is
+    used, so the results agree to 1e-9 where the iteration counts do and against the posterior spread elsewhere; the
+    scenes are the ones whose last iterations are rejected steps."""
+    import torch
+    from visualslam_amd import api
+    from visualslam_amd import synthetic as syn
+    L, B = 150, 6
+    scs = [syn.Scene(L, 9000 + i, dense_S=True) for i in range(B)]
+    rng = np.random.default_rng(1)
+    mus = np.stack([sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)])
+                    for sc in scs])
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    y = torch.tensor(np.stack([sc.y for sc in scs]), device=dev)
+    vis = torch.tensor(np.stack([sc.visible for sc in scs]).astype(np.uint8), device=dev)
+    out = []
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("VSLAM_BANK_SOLVE_AHEAD", ahead)
+        mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+        code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, scs[0].sigma, mup, Sp)
+        torch.cuda.synchronize()
+        out.append((np.array(code), np.array(iters), np.array(status), mup.cpu().numpy(), Sp.cpu().numpy()))
+    (c1, i1, s1, m1, S1), (c0, i0, s0, m0, S0) = out
+    assert np.array_equal(s1, s0) and np.array_equal(c1[s0 == 0], c0[s0 == 0])
+    assert (i0[s0 == 0] >= 7).any()                       # rejected steps did occur
+    for b in range(B):
+        if s0[b]:
+            continue
+        A0, A1 = S0[b].T, S1[b].T
+        if i1[b] == i0[b]:
+            assert np.abs(m1[b] - m0[b]).max() <= 1e-9 * max(1.0, np.abs(m0[b]).max())
+            assert rel_err(A1.T @ A1, A0.T @ A0) <= 1e-9
+        else:
+            assert np.linalg.norm(np.linalg.solve(A0.T, m1[b] - m0[b])) <= 1e-6
+            assert rel_err(A1.T @ A1, A0.T @ A0) <= 1e-6
