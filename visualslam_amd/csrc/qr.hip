@@ -549,7 +549,7 @@ static int block_width(int rows, int cols, int batch)
 
 struct QrWs {
     double *T, *Wpart, *W2, *slots;
-    double *xbuf; unsigned *xflags;       // exchange area and flag words of qr_block_kernel
+    double *xbuf;                         // exchange area of qr_block_kernel
     double *Vbuf[2], *G[2], *Mo[2], *Gpart, *Wn, *Wnpart, *Wb, *Wbpart;   // outer-block path only (double-buffered per block parity)
 };
 
@@ -564,7 +564,6 @@ static void qr_carve(void *ws, int rows, int cols, int batch, QrWs *w)
         QrBlockPlan pl;
         const bool ok = qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl);
         w->xbuf = ar.take<double>(ok ? (size_t)batch * pl.xbuf_doubles : 1);
-        w->xflags = ar.take<unsigned>(ok ? (size_t)batch * pl.flag_words : 1);
     }
     if (use_outer_blocks(rows, cols, batch)) {
         for (int i = 0; i < 2; ++i) {
@@ -589,7 +588,7 @@ size_t qr_ws_bytes(int rows, int cols, int batch)
     {
         QrBlockPlan pl;
         const bool ok = qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl);
-        coop += Arena::pad((ok ? (size_t)batch * pl.xbuf_doubles : 1) * 8) + Arena::pad((ok ? (size_t)batch * pl.flag_words : 1) * 4);
+        coop += Arena::pad((ok ? (size_t)batch * pl.xbuf_doubles : 1) * 8);
     }
     size_t big = 0;
     if (use_outer_blocks(rows, cols, batch))
@@ -625,7 +624,7 @@ static vslam_status qr_factor_panel(QrJob &q, int j, int jb, double *Tdst, doubl
         if (Vout && vzero > 0)
             VSLAM_HIP_TRY(q.ctx, hipMemset2DAsync(Vout - vzero, (size_t)ldv * 8, 0, (size_t)vzero * 8, (size_t)jb, s));
         return qr_block_launch(q.ctx, s, q.pl, P, q.lda, q.strideA, q.batch, mp, jb, jb, seq0, Tdst, (size_t)MSTRIDE, Vout, ldv,
-                               q.w.xbuf, q.w.xflags);
+                               q.w.xbuf);
     }
     if (q.rows_per > 0 || mp <= CP_RMAX) {
         // A panel of at most CP_RMAX rows fits one workgroup's LDS: no exchange, any batch.
@@ -916,10 +915,10 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
     const unsigned seq0 = 256u * q.launches++;
     if (blk == 0)
         VSLAM_TRY(qr_block_launch(ctx, s, q.pl, q.A + (size_t)j0 * q.lda + j0, q.lda, q.strideA, 1, mp0, ob, ob, seq0,
-                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf, q.w.xflags));
+                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf));
     else
         VSLAM_TRY(qr_block_launch(ctx, s, q.pl, q.A + (size_t)j0 * q.lda + (j0 - ob), q.lda, q.strideA, 1, mp0 + ob, ob, ob, seq0,
-                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf, q.w.xflags,
+                                  q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf,
                                   ob, q.w.Vbuf[par ^ 1], mp0 + ob, q.w.Mo[par ^ 1], ob / QR_NB));
     const int first = next_resident ? j0 + 2 * ob : j0 + ob;     // first column the side stream updates
     const int nside = q.cols - first;

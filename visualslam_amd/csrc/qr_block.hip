@@ -72,7 +72,6 @@ struct QbArgs {
     const double *Vprev; int ldvp;           // roff > 0: explicit reflectors of the previous block, element (first row of this launch, its column 0)
     const double *Tprev; int prev_np;        //           and its panels' T (QR_MSTRIDE apart); applied to the resident columns first
     double *xbuf; size_t xstride;            // exchange area per matrix: part [G][cmax], red [cmax], top [1024]
-    unsigned *flags; int fstride;            // per matrix: [2][fstride/2] flag words
     int cmax;
     int *err;
 };
@@ -996,7 +995,6 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
         p->cmax = bw > 32 ? 32 * bw : 1024;                    // W of one panel of reflectors against every resident column
         p->lds_bytes = lds < ((size_t)96 << 10) ? ((size_t)96 << 10) : lds;     // one workgroup per compute unit
         p->xbuf_doubles = 2 * ((size_t)(p->G + 1) * p->cmax + 1024);      // two words per value: contributions, sums, top rows
-        p->flag_words = 2 * ((p->G + 63) & ~63);
         return true;
     }
     return false;
@@ -1004,7 +1002,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
 
 vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPlan &pl, double *A, int lda, size_t strideA, int batch,
                              int mp, int bwc, int nfac, unsigned seq0, double *T, size_t strideT, double *V, int ldv,
-                             double *xbuf, unsigned *flags, int roff, const double *Vprev, int ldvp, const double *Tprev, int prev_np)
+                             double *xbuf, int roff, const double *Vprev, int ldvp, const double *Tprev, int prev_np)
 {
     if (bwc > pl.bw || nfac > bwc || nfac > mp || nfac < 1) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d columns (%d to factor) in a block of %d", bwc, nfac, pl.bw);
     const int G = (mp + pl.rows_per - 1) / pl.rows_per;
@@ -1034,7 +1032,7 @@ vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPl
         a.T = T + (size_t)b0 * strideT; a.strideT = strideT; a.V = V; a.ldv = ldv;
         a.roff = roff; a.Vprev = Vprev; a.ldvp = ldvp; a.Tprev = Tprev; a.prev_np = prev_np;
         a.xbuf = xbuf + (size_t)b0 * pl.xbuf_doubles; a.xstride = pl.xbuf_doubles;
-        a.flags = flags + (size_t)b0 * pl.flag_words; a.fstride = pl.flag_words; a.cmax = pl.cmax;
+        a.cmax = pl.cmax;
         a.err = ctx->flags;
         hipLaunchKernelGGL(qr_block_kernel, dim3(G, nb_), dim3(QB_T), pl.lds_bytes, stream, a);
     }

@@ -19,7 +19,6 @@ struct QrBlockPlan {
     int cmax;               // doubles per workgroup in the exchange buffer
     size_t lds_bytes;
     size_t xbuf_doubles;    // exchange buffer per matrix
-    int flag_words;         // flag words per matrix (zeroed before the first launch of a factorisation)
 };
 // False when no arrangement fits (batch > 8, or more rows than 240 workgroups can hold).
 bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p);
@@ -31,7 +30,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p);
 // there) and first applies the previous block's reflectors Vprev / Tprev (prev_np panels) to the resident columns.
 vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPlan &pl, double *A, int lda, size_t strideA, int batch,
                              int mp, int bwc, int nfac, unsigned seq0, double *T, size_t strideT, double *V, int ldv,
-                             double *xbuf, unsigned *flags, int roff = 0, const double *Vprev = nullptr, int ldvp = 0,
+                             double *xbuf, int roff = 0, const double *Vprev = nullptr, int ldvp = 0,
                              const double *Tprev = nullptr, int prev_np = 0);
 
 }  // namespace vslam
