@@ -289,6 +289,37 @@ def test_triangular_inverse_bank(ctx):
         assert not np.tril(W[b], -1).any()
 
 
+def _trsv(ctx, S_colmajor, trans, b):
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    S = np.ascontiguousarray(S_colmajor, dtype=np.float64)
+    n = S.shape[0]
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    z = np.full(n, np.nan)
+    fn = L.vslam_debug_trsv
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert fn(ctx.ptr, S.ctypes.data, n, int(trans), b.ctypes.data, z.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
+    return z
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 127, 128, 129, 200, 256, 257, 320, 462, 1000, 2100, 6012])
+@pytest.mark.parametrize("trans", [False, True])
+def test_triangular_vector_solve(ctx, n, trans):
+    """One block, every count of blocks around the reach of the chain workgroup (2 to 5 blocks: with and without
+    helper workgroups), ragged last blocks in both directions, and the sizes of the measurement update."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(3 * n + int(trans))
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + np.diag((1.0 + rng.random(n)) * rng.choice([-1.0, 1.0], n))
+    garbage = U + np.tril(rng.standard_normal((n, n)), -1)             # the strict lower triangle must not be read
+    b = rng.standard_normal(n)
+    z = _trsv(ctx, np.ascontiguousarray(garbage.T), trans, b)
+    z0 = sla.solve_triangular(U, b, trans=1 if trans else 0, lower=False)
+    assert rel_err(z, z0) <= 1e-11
+    res = (U.T @ z if trans else U @ z) - b
+    assert np.abs(res).max() <= 1e-11 * max(1.0, np.abs(z).max()) * np.sqrt(n)
+
+
 def _potrf(ctx, A, rhs=None):
     from visualslam_amd import _lib
     L = _lib.lib()

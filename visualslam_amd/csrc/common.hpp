@@ -15,7 +15,7 @@
 // A device-to-host copy staged in pinned memory, finished (pinned -> caller's buffer) after the stream drains.
 struct vslam_pending_copy { void *dst; const void *src; size_t width, height, dpitch; };
 
-constexpr int VSLAM_CHAIN_SOL_DOUBLES = 240 * 64;   // the chained triangular solve handles up to 240 blocks of 64
+constexpr int VSLAM_CHAIN_SOL_DOUBLES = 2 * 240 * 64;   // the chained triangular solve handles up to 240 blocks of 64 (solutions, then helper sums)
 
 struct vslam_ctx {
     int device = 0;

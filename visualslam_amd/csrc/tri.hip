@@ -190,99 +190,299 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
     }
 }
 
-// The same solve in ONE launch for up to TC_MAX diagonal blocks: workgroup i owns the i-th block in
-// dependency order (trans: first to last; otherwise last to first).  It adds up the contributions of the
-// blocks before it as their solutions appear (coefficients are fetched ahead of the wait: they do not
-// depend on it), solves its own 64 x 64 block in one wave and publishes the 64 entries.  Only the chain of
-// diagonal solves is sequential; the off-diagonal work of all workgroups overlaps it.
-// A solution entry is its own ready mark: `sol` is filled with a NaN of all-ones bits before the launch and a
-// reader polls the entries it needs until none of them carries that pattern any more, so a link of the chain costs
-// one trip through memory (the entries themselves), not a flag and then the data.  (A solution that is itself this
-// NaN -- only a right-hand side holding the same pattern produces one -- ends in the bounded wait below.)
-// All workgroups are resident together (TC_MAX <= 240 of 256 compute units), a wait that exceeds its bound raises
-// *err and lets every wave run to the end.
+// The same solve in ONE launch for up to TC_MAX diagonal blocks.  Blocks are numbered in dependency order
+// (position 0 first: the first block when trans, the last otherwise) and inside a block the entries are numbered
+// the same way (slot 0 first), so both solves read as "entry k feeds every later entry".
+//
+// Workgroup 0 walks the whole chain and never waits for another workgroup on its critical path:
+//   * its last wave substitutes through the 64 x 64 diagonal block held in LDS, already scaled by the reciprocal
+//     pivots, so that a step of the chain is one lane broadcast and one multiply-add; the same step feeds the
+//     coupling block towards the next position (a second, independent multiply-add), which takes the newest
+//     solution block off the critical path altogether;
+//   * its eight other waves meanwhile prepare the next position: the contributions of the positions 2 ... TC_LAG-1
+//     back (coefficients fetched one link ahead, solution blocks from LDS), the scaled diagonal and coupling
+//     blocks, and the sum over everything further back, which a helper workgroup supplies.
+// Helper workgroup b accumulates, for position TC_LAG-1+b, the contributions of all positions at least TC_LAG
+// back as their solutions appear and publishes the 64 sums.  Those travel through memory (two trips and a little
+// arithmetic), which the TC_LAG-1 links in between cover.
+// Published values are their own ready marks: `sol` (solutions, then sums) is filled with a NaN of all-ones bits
+// before the launch and a reader polls until the pattern is gone.  (A value that is itself this NaN -- only a
+// right-hand side holding the same pattern produces one -- ends in the bounded wait below.)  All workgroups are
+// resident together (at most TC_MAX of 256 compute units, one workgroup each); a wait that exceeds its bound
+// raises *err and lets every wave run to the end.
 constexpr int TC_MAX = 240;
-static_assert(TC_MAX * TBK <= VSLAM_CHAIN_SOL_DOUBLES, "solution buffer of the context");
-__global__ __launch_bounds__(256) void trsv_chain_kernel(const double *S, int n, int ldS, int trans, double *z, double *sol, int *err)
-{
-    __shared__ double U[TBK][TBK + 1];
-    __shared__ double part[4][TBK];
-    const int tid = threadIdx.x, c = tid & 63, p = tid >> 6;
-    const int nblk = (n + TBK - 1) / TBK;
-    const int w = trans ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
-    const int i0 = w * TBK, ib = min(TBK, n - i0);
+constexpr int TC_LAG = 4;
+constexpr int TC_T = 576;                                     // eight preparing waves and the chain wave
+constexpr int TCS = TBK + 1;                                  // row stride of the staged blocks in LDS
+constexpr int TC_LDS_DOUBLES = 4 * TBK * TCS + 2 * TBK + 16 * TBK + 4 * TBK + TC_LAG * TBK;
+static_assert(2 * TC_MAX * TBK <= VSLAM_CHAIN_SOL_DOUBLES, "solution buffer of the context");
+
+struct ChainGeo {
+    const double *S; int n, ldS, trans, nblk;
+    // global index of slot `slot` of position `pos`, or -1 outside the matrix
+    __device__ __forceinline__ int at(int pos, int slot) const
     {
-        double v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int idx = tid + 256 * j, r = idx % TBK, cc = idx / TBK;
-            v[j] = (r <= cc && cc < ib) ? S[(size_t)(i0 + cc) * ldS + i0 + r] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int idx = tid + 256 * j;
-            U[idx % TBK][idx / TBK] = v[j];
-        }
+        if (pos < 0 || pos >= nblk) return -1;
+        const int idx = trans ? pos * TBK + slot : (nblk - 1 - pos) * TBK + (TBK - 1 - slot);
+        return idx < n ? idx : -1;
     }
-    const double rhs = (tid < ib) ? z[i0 + tid] : 0.0;          // own right-hand side: fetched before any waiting
-    // thread (c, p): own entry c, entries 16p..16p+15 of the other block
-    double acc = 0.0;
+    // The coefficient with which source slot k of position ps enters the equation of slot l of position pd, for a
+    // thread whose lane runs along the memory rows (trans: lane = k and l = lu; otherwise lane = l and k = lu, lu
+    // the same for the whole wave).  raw() fetches without branches from indices clamped into the matrix (so that
+    // many fetches stay in flight together); live() tells whether the coefficient exists at all.
+    __device__ __forceinline__ void where(int ps, int pd, int lane, int lu, int &row, int &col) const
+    {
+        const int pr = trans ? ps : pd, pc = trans ? pd : ps;            // positions of the memory row and column
+        row = trans ? pr * TBK + lane : (nblk - 1 - pr) * TBK + (TBK - 1 - lane);
+        col = trans ? pc * TBK + lu : (nblk - 1 - pc) * TBK + (TBK - 1 - lu);
+    }
+    template <bool CLAMP = true>
+    __device__ __forceinline__ double raw(int ps, int pd, int lane, int lu) const
+    {
+        int row, col;
+        where(ps, pd, lane, lu, row, col);
+        if (CLAMP) { row = min(max(row, 0), n - 1); col = min(max(col, 0), n - 1); }
+        return S[(size_t)col * ldS + row];
+    }
+    // True when the positions lo ... hi all exist and hold 64 entries each: nothing to clamp, nothing to mask.
+    __device__ __forceinline__ bool whole(int lo, int hi) const
+    {
+        const bool ragged = (n % TBK) != 0;                              // the last block of the matrix is short
+        return lo >= 0 && hi < nblk && !(ragged && (trans ? hi == nblk - 1 : lo == 0));
+    }
+    __device__ __forceinline__ bool live(int ps, int pd, int lane, int lu) const
+    {
+        int row, col;
+        where(ps, pd, lane, lu, row, col);
+        return ps >= 0 && pd < nblk && row < n && col < n;
+    }
+};
+
+// Polls one published value; false once the launch has been declared dead.
+__device__ __forceinline__ double chain_wait(const double *p, int *err, bool &dead)
+{
+    unsigned spins = 0;
+    for (;;) {
+        const double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__double_as_longlong(v) != -1ll || dead) return v;
+        if ((++spins & 255u) == 0) {
+            if (spins > (1u << 22)) atomicExch(err, 1);
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// Sum over the 64 lanes of each of v[0..7]; on return every lane holds the total of v[j] for
+// j = 4 (lane bit 5) + 2 (lane bit 4) + (lane bit 3).  Ten exchanges instead of forty-eight.
+__device__ __forceinline__ double chain_reduce8(const double (&v)[8], int lane)
+{
+    double a[4], b[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = (h5 ? v[m + 4] : v[m]) + __shfl_xor(h5 ? v[m] : v[m + 4], 32);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) b[m] = (h4 ? a[m + 2] : a[m]) + __shfl_xor(h4 ? a[m] : a[m + 2], 16);
+    double c = (h3 ? b[1] : b[0]) + __shfl_xor(h3 ? b[0] : b[1], 8);
+    c += __shfl_xor(c, 4);
+    c += __shfl_xor(c, 2);
+    c += __shfl_xor(c, 1);
+    return c;
+}
+
+// Thread (lane, w, j) of the preparing waves and of the helpers handles the coefficient of source slot k in the
+// equation of slot l, with the lanes along whichever of the two is contiguous in memory:
+//   trans:  k = lane, l = 8 w + j        otherwise:  l = lane, k = 8 w + j.
+template <bool trans>
+__global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, double *z, double *sol, int *err)
+{
+    extern __shared__ double tc_lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, w = wave & 7;
+    ChainGeo g{S, n, ldS, trans, (n + TBK - 1) / TBK};
+    double *sums = sol + (size_t)g.nblk * TBK;                   // helper sums, one block of 64 per position
     bool dead = false;
-    for (int s = 0; s < (int)blockIdx.x; ++s) {
-        const int v = trans ? s : nblk - 1 - s;
-        const int v0 = v * TBK;                                   // the last block may be short: entries j >= n are skipped
-        double coef[16];
+    const int jl = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);     // whose total chain_reduce8 leaves here
+
+    if (blockIdx.x > 0) {
+        // helper: everything at least TC_LAG positions back, for position pos
+        const int pos = TC_LAG - 1 + (int)blockIdx.x;
+        double *part = tc_lds;                                   // [8][64]
+        if (wave < 8) {
+            double acc[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int j = v0 + 16 * p + e;
-            // trans: U(j, i0 + c)  (rows of the earlier block, own column);  otherwise U(i0 + c, j)
-            coef[e] = (c < ib && j < n) ? (trans ? S[(size_t)(i0 + c) * ldS + j] : S[(size_t)j * ldS + i0 + c]) : 0.0;
-        }
-        double zv[16];
-        unsigned spins = 0;
-        for (;;) {
-            bool ok = true;
+            for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+            for (int s = 0; s + TC_LAG <= pos; ++s) {
+                double cf[8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int j = min(v0 + 16 * p + e, n - 1);
-                zv[e] = __hip_atomic_load(&sol[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (__double_as_longlong(zv[e]) != -1ll);
+                for (int j = 0; j < 8; ++j) cf[j] = g.raw(s, pos, lane, 8 * w + j);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cf[j] = g.live(s, pos, lane, 8 * w + j) ? cf[j] : 0.0;
+                if (trans) {
+                    const double x = chain_wait(sol + (size_t)s * TBK + lane, err, dead);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += cf[j] * x;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += cf[j] * chain_wait(sol + (size_t)s * TBK + 8 * w + j, err, dead);
+                }
             }
-            if (ok || dead) break;
-            if ((++spins & 255u) == 0) {
-                if (spins > (1u << 22)) atomicExch(err, 1);
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) dead = true;
+            if (trans) {
+                const double tot = chain_reduce8(acc, lane);
+                if ((lane & 7) == 0)
+                    __hip_atomic_store(&sums[(size_t)pos * TBK + 8 * w + jl], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                part[w * TBK + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
             }
-            __builtin_amdgcn_s_sleep(1);
         }
+        if (!trans) {
+            __syncthreads();
+            if (tid < TBK) {
+                double h = 0.0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc += coef[e] * zv[e];      // coefficients beyond the matrix are zero
+                for (int q = 0; q < 8; ++q) h += part[q * TBK + tid];
+                __hip_atomic_store(&sums[(size_t)pos * TBK + tid], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
     }
-    part[p][c] = acc;
-    __syncthreads();
-    if (tid < 64) {
-        double v = (tid < ib) ? rhs - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) : 0.0;
-        // substitution with the running right-hand side in the lanes; the pivot lane's value and the
-        // reciprocal of its diagonal entry are broadcast with v_readlane (the chain per step is
-        // readlane -> multiply -> multiply-add)
-        const double rinv = 1.0 / U[tid][tid];                      // rows past ib hold a zero diagonal: unused
+
+    double *Cs = tc_lds;                          // [2][64][TCS] diagonal block, scaled, row = source slot
+    double *Bs = Cs + 2 * TBK * TCS;              // [2][64][TCS] coupling towards the next position, scaled
+    double *rb = Bs + 2 * TBK * TCS;              // [2][64] trans: right-hand side of a position without its newest contribution
+    double *part = rb + 2 * TBK;                  // [2][8][64] otherwise: the same in eight parts, negated
+    double *rinvs = part + 2 * 8 * TBK;           // [4][64] reciprocal pivots
+    double *xring = rinvs + 4 * TBK;              // [TC_LAG][64] the latest solution blocks
+
+    double cst[8], bst[8], tcf[TC_LAG - 2][8], zr = 0.0, dgl = 1.0;
+    const bool zlane = trans ? (lane & 7) == 0 : w == 0;          // lanes that finish a right-hand side entry
+    const int zslot = trans ? 8 * w + jl : lane;
+    auto diag_of = [&](int pos) {
+        const int a = g.at(pos, lane);
+        return (a >= 0) ? S[(size_t)a * ldS + a] : 1.0;
+    };
+    auto load_stage = [&](int pos) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            cst[j] = g.raw(pos, pos, lane, 8 * w + j);
+            bst[j] = g.raw(pos, pos + 1, lane, 8 * w + j);
+        }
+    };
+    auto load_terms = [&](int pos) {
+#pragma unroll
+        for (int d = 2; d < TC_LAG; ++d)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tcf[d - 2][j] = g.raw(pos - d, pos, lane, 8 * w + j);
+        const int c = g.at(pos, zslot);
+        zr = (zlane && c >= 0) ? z[c] : 0.0;
+    };
+    auto do_stage = [&](int pos) {
+        const int par = pos & 1;
+        const double *ri = rinvs + (pos & 3) * TBK;
+        const bool whole = g.whole(pos, pos + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lu = 8 * w + j, k = trans ? lane : lu, l = trans ? lu : lane;
+            const double rinv = ri[k];
+            // source slot before destination slot
+            Cs[(par * TBK + k) * TCS + l] = (k < l && (whole || g.live(pos, pos, lane, lu))) ? cst[j] * rinv : 0.0;
+            Bs[(par * TBK + k) * TCS + l] = (whole || g.live(pos, pos + 1, lane, lu)) ? bst[j] * rinv : 0.0;
+        }
+    };
+    auto do_terms = [&](int pos) {
+        double pr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pr[j] = 0.0;
+        const bool whole = g.whole(pos - (TC_LAG - 1), pos);
+#pragma unroll
+        for (int d = 2; d < TC_LAG; ++d) {
+            const int src = pos - d;
+            if (src >= 0) {
+                const double *x = xring + (src % TC_LAG) * TBK;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pr[j] += ((whole || g.live(src, pos, lane, 8 * w + j)) ? tcf[d - 2][j] : 0.0) * x[trans ? lane : 8 * w + j];
+            }
+        }
+        double h = 0.0;
+        if (zlane && pos >= TC_LAG) h = chain_wait(sums + (size_t)pos * TBK + zslot, err, dead);
         if (trans) {
-            for (int k = 0; k < ib; ++k) {
-                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
-                if (tid > k) v -= U[k][tid] * xk;
-                else if (tid == k) v = xk;
-            }
+            const double tot = chain_reduce8(pr, lane);
+            if (zlane) rb[(pos & 1) * TBK + zslot] = zr - h - tot;
         } else {
-            for (int k = ib - 1; k >= 0; --k) {
-                const double xk = readlane_f64(v, k) * readlane_f64(rinv, k);
-                if (tid < k) v -= U[tid][k] * xk;
-                else if (tid == k) v = xk;
+            double acc = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+            if (zlane) acc -= zr - h;
+            part[((pos & 1) * 8 + w) * TBK + lane] = acc;
+        }
+    };
+    // The preparing waves keep their fetches for the next link in flight across the barrier: it orders LDS only.
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+
+    if (wave < 8) {
+        if (wave == 7) {
+            rinvs[0 * TBK + lane] = 1.0 / diag_of(0);
+            rinvs[1 * TBK + lane] = 1.0 / diag_of(1);
+            dgl = diag_of(2);
+        }
+        load_stage(0);
+        load_terms(0);
+    }
+    lds_barrier();
+    if (wave < 8) {
+        do_terms(0);
+        do_stage(0);
+        load_stage(1);
+        load_terms(1);
+    }
+    lds_barrier();
+    double nacc = 0.0;                                            // chain wave: what the block just solved adds to the next one
+    // Two loops, one per role, meeting at the same barriers: neither role carries the other's registers.
+    if (wave == 8) {
+        for (int i = 0; i < g.nblk; ++i) {
+            const int par = i & 1;
+            const double *C = Cs + par * TBK * TCS + lane, *B = Bs + par * TBK * TCS + lane;
+            double v;
+            if (trans) {
+                v = rb[par * TBK + lane] - nacc;
+            } else {
+                const double *q = part + par * 8 * TBK + lane;
+                v = -(((q[0] + q[TBK]) + (q[2 * TBK] + q[3 * TBK])) + ((q[4 * TBK] + q[5 * TBK]) + (q[6 * TBK] + q[7 * TBK]))) - nacc;
             }
+            nacc = 0.0;
+            // the coefficients of a step are fetched from LDS eight steps ahead, into the registers the step just freed
+            double c8[8], b8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c8[q] = C[q * TCS]; b8[q] = B[q * TCS]; }
+#pragma unroll
+            for (int k = 0; k < TBK; ++k) {
+                const double yk = readlane_f64(v, k);
+                v = fma(-c8[k & 7], yk, v);
+                nacc = fma(b8[k & 7], yk, nacc);
+                if (k + 8 < TBK) { c8[k & 7] = C[(k + 8) * TCS]; b8[k & 7] = B[(k + 8) * TCS]; }
+            }
+            const int c = g.at(i, lane);
+            const double x = (c >= 0) ? v * rinvs[(i & 3) * TBK + lane] : 0.0;
+            xring[(i % TC_LAG) * TBK + lane] = x;
+            __hip_atomic_store(&sol[(size_t)i * TBK + lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c >= 0) z[c] = x;
+            lds_barrier();
         }
-        if (tid < ib) {
-            __hip_atomic_store(&sol[i0 + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            z[i0 + tid] = v;                                         // nobody else reads or writes this block of z
+        return;
+    }
+    for (int i = 0; i < g.nblk; ++i) {
+        if (i + 1 < g.nblk) {
+            do_terms(i + 1);
+            do_stage(i + 1);
+            if (wave == 7) {
+                rinvs[((i + 2) & 3) * TBK + lane] = 1.0 / dgl;
+                dgl = diag_of(i + 3);
+            }
+            load_stage(i + 2);
+            load_terms(i + 2);
         }
+        lds_barrier();
     }
 }
 
@@ -292,8 +492,13 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
     if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     const int nblk = (n + TBK - 1) / TBK;
     if (nblk > 1 && nblk <= TC_MAX) {
-        VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, (size_t)n * 8, s));
-        hipLaunchKernelGGL(trsv_chain_kernel, dim3(nblk), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, z, ctx->chain_sol, ctx->flags);
+        const size_t lds = (size_t)TC_LDS_DOUBLES * 8;
+        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, (size_t)2 * nblk * TBK * 8, s));
+        const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
+        if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, z, ctx->chain_sol, ctx->flags);
+        else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, z, ctx->chain_sol, ctx->flags);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     }
@@ -327,5 +532,23 @@ extern "C" vslam_status vslam_debug_trtri(vslam_ctx *ctx, const double *S, int n
     if (batch == 1) VSLAM_TRY(trtri_upper_dev(ctx, dS, n, n, dW, n, w));
     else VSLAM_TRY(trtri_upper_batch_dev(ctx, dS, n, n, nn, dW, n, nn, batch, w));
     VSLAM_TRY(d2h(ctx, W, dW, bytes));
+    return stream_finish(ctx);
+}
+
+// Test hook (not part of the public header): z = S^-1 b (trans = 0) or S^-T b (trans = 1) for one upper-triangular
+// n x n matrix on the host (column-major, ld n).
+extern "C" vslam_status vslam_debug_trsv(vslam_ctx *ctx, const double *S, int n, int trans, const double *b, double *z)
+{
+    using namespace vslam;
+    if (!ctx || !S || !b || !z || n < 1) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(nn * 8) + 2 * Arena::pad((size_t)n * 8)));
+    Arena ar(ctx->ws);
+    double *dS = ar.take<double>(nn), *db = ar.take<double>(n), *dz = ar.take<double>(n);
+    VSLAM_TRY(h2d(ctx, dS, S, nn * 8));
+    VSLAM_TRY(h2d(ctx, db, b, (size_t)n * 8));
+    VSLAM_TRY(trsv_upper_dev(ctx, dS, n, n, trans != 0, db, dz));
+    VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));
     return stream_finish(ctx);
 }
