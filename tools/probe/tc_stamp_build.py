@@ -22,14 +22,14 @@ def rep(a, b):
 
 
 rep("    double nacc = 0.0; ", "    long long *stamps = reinterpret_cast<long long *>(sol) + 16384;\n    double nacc = 0.0; ")
-rep("        for (int i = 0; i < g.nblk; ++i) {\n            const int par = i & 1;", "        for (int i = 0; i < g.nblk; ++i) {\n            if (lane == 0) stamps[i * 8 + 0] = wall_clock64();\n            const int par = i & 1;")
-rep("            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs", "            if (lane == 0) stamps[i * 8 + 1] = wall_clock64();\n            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs")
-rep("        if (i + 1 < g.nblk) {\n            do_terms(i + 1);\n            do_stage(i + 1);",
-    "        if (i + 1 < g.nblk) {\n            if (tid == 0) stamps[i * 8 + 2] = wall_clock64();\n            do_terms(i + 1);\n            if (tid == 0) stamps[i * 8 + 3] = wall_clock64();\n            do_stage(i + 1);\n            if (tid == 0) stamps[i * 8 + 4] = wall_clock64();")
-rep("            load_stage(i + 2);\n            load_terms(i + 2);\n        }\n        lds_barrier();\n    }\n}",
-    "            load_stage(i + 2);\n            load_terms(i + 2);\n            if (tid == 0) stamps[i * 8 + 5] = wall_clock64();\n        }\n        lds_barrier();\n    }\n}")
+rep("        for (int i = 0; i < g.nblk; ++i) {\n            const int par = i & 1;", "        for (int i = 0; i < g.nblk; ++i) {\n            if (lane == 0) stamps[i * 16 + 0] = wall_clock64();\n            const int par = i & 1;")
+rep("            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs", "            if (lane == 0 && v != 1234.5678) stamps[i * 16 + 1] = wall_clock64();\n            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs")
+rep("            const double acc = do_terms(i + 1);",
+    "            if (tid == 0) stamps[i * 16 + 2] = wall_clock64();\n            const double acc = do_terms(i + 1);\n            if (tid == 0 && acc != 1234.5678) stamps[i * 16 + 3] = stamps[i * 16 + 4] = wall_clock64();")
+rep("            finish_terms(i + 1, acc, h, zv);\n        }\n        lds_barrier();\n    }\n}",
+    "            finish_terms(i + 1, acc, h, zv);\n            if (tid == 0) stamps[i * 16 + 5] = wall_clock64();\n            if (lane == 0) stamps[i * 16 + 6 + wave] = wall_clock64();\n        }\n        lds_barrier();\n    }\n}")
 rep("    VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));\n    return stream_finish(ctx);",
-    "    VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));\n    if (getenv(\"TC_STAMPS\")) { static long long st[8 * 240]; VSLAM_TRY(d2h(ctx, st, ctx->chain_sol + 16384, sizeof(st))); VSLAM_TRY(stream_finish(ctx)); FILE *f = fopen(getenv(\"TC_STAMPS\"), \"w\"); for (int i = 0; i < 240; ++i) { for (int q = 0; q < 6; ++q) fprintf(f, \"%lld \", st[i * 8 + q]); fprintf(f, \"\\n\"); } fclose(f); }\n    return stream_finish(ctx);")
+    "    VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));\n    if (getenv(\"TC_STAMPS\")) { static long long st[16 * 240]; VSLAM_TRY(d2h(ctx, st, ctx->chain_sol + 16384, sizeof(st))); VSLAM_TRY(stream_finish(ctx)); FILE *f = fopen(getenv(\"TC_STAMPS\"), \"w\"); for (int i = 0; i < 240; ++i) { for (int q = 0; q < 14; ++q) fprintf(f, \"%lld \", st[i * 16 + q]); fprintf(f, \"\\n\"); } fclose(f); }\n    return stream_finish(ctx);")
 s = s.replace('#include "linalg.hpp"', '#include "linalg.hpp"\n#include <cstdio>\n#include <cstdlib>', 1)
 open(p, "w").write(s)
 subprocess.check_call(["make", "-C", dst + "/visualslam_amd/csrc", "OUT=" + root + "/tools/probe/libvslam_hip_tc.so"], stdout=subprocess.DEVNULL)

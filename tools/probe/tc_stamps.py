@@ -31,4 +31,4 @@ print("link: chain start, chain loop end | workers: start, terms done, stage don
 for i in list(range(0, 8)) + list(range(40, 48)):
     if i >= nblk - 1: break
     r = st[i]
-    print(i, "%.2f" % ((r[0] - t0) / 100.0), " ".join("%.2f" % ((x - r[0]) / 100.0) for x in r[1:6]), " next link after %.2f" % ((st[i + 1, 0] - r[0]) / 100.0))
+    print(i, "%.2f" % ((r[0] - t0) / 100.0), " ".join("%.2f" % ((x - r[0]) / 100.0) for x in r[1:6]), "| waves at barrier", " ".join("%.2f" % ((x - r[0]) / 100.0) for x in r[6:14]), "| next link after %.2f" % ((st[i + 1, 0] - r[0]) / 100.0))

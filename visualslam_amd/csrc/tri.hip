@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
 // resident together (at most TC_MAX of 256 compute units, one workgroup each); a wait that exceeds its bound
 // raises *err and lets every wave run to the end.
 constexpr int TC_MAX = 240;
-constexpr int TC_LAG = 4;
+constexpr int TC_LAG = 3;
 constexpr int TC_T = 576;                                     // eight preparing waves and the chain wave
 constexpr int TCS = TBK + 1;                                  // row stride of the staged blocks in LDS
 constexpr int TC_LDS_DOUBLES = 4 * TBK * TCS + 2 * TBK + 16 * TBK + 4 * TBK + TC_LAG * TBK;
@@ -292,7 +292,8 @@ __device__ __forceinline__ double chain_reduce8(const double (&v)[8], int lane)
 
 // Thread (lane, w, j) of the preparing waves and of the helpers handles the coefficient of source slot k in the
 // equation of slot l, with the lanes along whichever of the two is contiguous in memory:
-//   trans:  k = lane, l = 8 w + j        otherwise:  l = lane, k = 8 w + j.
+//   trans:  k = lane, l = w + 8 j        otherwise:  l = lane, k = w + 8 j
+// (interleaved over the waves: the triangular diagonal block then gives every wave the same share).
 template <bool trans>
 __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, double *z, double *sol, int *err)
 {
@@ -314,22 +315,22 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             for (int s = 0; s + TC_LAG <= pos; ++s) {
                 double cf[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cf[j] = g.raw(s, pos, lane, 8 * w + j);
+                for (int j = 0; j < 8; ++j) cf[j] = g.raw(s, pos, lane, w + 8 * j);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cf[j] = g.live(s, pos, lane, 8 * w + j) ? cf[j] : 0.0;
+                for (int j = 0; j < 8; ++j) cf[j] = g.live(s, pos, lane, w + 8 * j) ? cf[j] : 0.0;
                 if (trans) {
                     const double x = chain_wait(sol + (size_t)s * TBK + lane, err, dead);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] += cf[j] * x;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += cf[j] * chain_wait(sol + (size_t)s * TBK + 8 * w + j, err, dead);
+                    for (int j = 0; j < 8; ++j) acc[j] += cf[j] * chain_wait(sol + (size_t)s * TBK + w + 8 * j, err, dead);
                 }
             }
             if (trans) {
                 const double tot = chain_reduce8(acc, lane);
                 if ((lane & 7) == 0)
-                    __hip_atomic_store(&sums[(size_t)pos * TBK + 8 * w + jl], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sums[(size_t)pos * TBK + w + 8 * jl], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 part[w * TBK + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
             }
@@ -355,63 +356,132 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
 
     double cst[8], bst[8], tcf[TC_LAG - 2][8], zr = 0.0, dgl = 1.0;
     const bool zlane = trans ? (lane & 7) == 0 : w == 0;          // lanes that finish a right-hand side entry
-    const int zslot = trans ? 8 * w + jl : lane;
+    const int zslot = trans ? w + 8 * jl : lane;
     auto diag_of = [&](int pos) {
         const int a = g.at(pos, lane);
         return (a >= 0) ? S[(size_t)a * ldS + a] : 1.0;
     };
+    // Whole blocks (the rule; only the ends of the chain and a short last block differ) take a short way: one
+    // address per block and thread, the eight coefficients a fixed stride apart, no clamping and no masks.
+    const ptrdiff_t sj = trans ? 8 * (ptrdiff_t)ldS : -8 * (ptrdiff_t)ldS;       // from one of the thread's eight slots to the next
+    auto block_ptr = [&](int ps, int pd) {
+        int row, col;
+        g.where(ps, pd, lane, w, row, col);
+        return S + (size_t)col * ldS + row;
+    };
     auto load_stage = [&](int pos) {
+        if (g.whole(pos, pos + 1)) {
+            const double *pc = block_ptr(pos, pos), *pb = block_ptr(pos, pos + 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            cst[j] = g.raw(pos, pos, lane, 8 * w + j);
-            bst[j] = g.raw(pos, pos + 1, lane, 8 * w + j);
+            for (int j = 0; j < 8; ++j) { cst[j] = pc[j * sj]; bst[j] = pb[j * sj]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cst[j] = g.raw(pos, pos, lane, w + 8 * j);
+                bst[j] = g.raw(pos, pos + 1, lane, w + 8 * j);
+            }
         }
     };
     auto load_terms = [&](int pos) {
+        if (g.whole(pos - (TC_LAG - 1), pos)) {
 #pragma unroll
-        for (int d = 2; d < TC_LAG; ++d)
+            for (int d = 2; d < TC_LAG; ++d) {
+                const double *pt = block_ptr(pos - d, pos);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tcf[d - 2][j] = g.raw(pos - d, pos, lane, 8 * w + j);
+                for (int j = 0; j < 8; ++j) tcf[d - 2][j] = pt[j * sj];
+            }
+        } else {
+#pragma unroll
+            for (int d = 2; d < TC_LAG; ++d)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tcf[d - 2][j] = g.raw(pos - d, pos, lane, w + 8 * j);
+        }
         const int c = g.at(pos, zslot);
         zr = (zlane && c >= 0) ? z[c] : 0.0;
     };
     auto do_stage = [&](int pos) {
         const int par = pos & 1;
         const double *ri = rinvs + (pos & 3) * TBK;
-        const bool whole = g.whole(pos, pos + 1);
+        if (g.whole(pos, pos + 1)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int lu = 8 * w + j, k = trans ? lane : lu, l = trans ? lu : lane;
-            const double rinv = ri[k];
-            // source slot before destination slot
-            Cs[(par * TBK + k) * TCS + l] = (k < l && (whole || g.live(pos, pos, lane, lu))) ? cst[j] * rinv : 0.0;
-            Bs[(par * TBK + k) * TCS + l] = (whole || g.live(pos, pos + 1, lane, lu)) ? bst[j] * rinv : 0.0;
+            for (int j = 0; j < 8; ++j) {
+                const int lu = w + 8 * j, k = trans ? lane : lu, l = trans ? lu : lane;
+                const double rinv = ri[k], cv = cst[j] * rinv;
+                Cs[(par * TBK + k) * TCS + l] = (k < l) ? cv : 0.0;          // source slot before destination slot
+                Bs[(par * TBK + k) * TCS + l] = bst[j] * rinv;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lu = w + 8 * j, k = trans ? lane : lu, l = trans ? lu : lane;
+                const double rinv = ri[k], cv = cst[j] * rinv, bv = bst[j] * rinv;
+                Cs[(par * TBK + k) * TCS + l] = (k < l && g.live(pos, pos, lane, lu)) ? cv : 0.0;
+                Bs[(par * TBK + k) * TCS + l] = g.live(pos, pos + 1, lane, lu) ? bv : 0.0;
+            }
         }
     };
-    auto do_terms = [&](int pos) {
+    auto do_terms = [&](int pos) -> double {
         double pr[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) pr[j] = 0.0;
-        const bool whole = g.whole(pos - (TC_LAG - 1), pos);
+        if (g.whole(pos - (TC_LAG - 1), pos)) {
 #pragma unroll
-        for (int d = 2; d < TC_LAG; ++d) {
-            const int src = pos - d;
-            if (src >= 0) {
-                const double *x = xring + (src % TC_LAG) * TBK;
+            for (int d = 2; d < TC_LAG; ++d) {
+                const double *x = xring + ((pos - d) % TC_LAG) * TBK;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pr[j] += ((whole || g.live(src, pos, lane, 8 * w + j)) ? tcf[d - 2][j] : 0.0) * x[trans ? lane : 8 * w + j];
+                for (int j = 0; j < 8; ++j) pr[j] = fma(tcf[d - 2][j], x[trans ? lane : w + 8 * j], pr[j]);
+            }
+        } else {
+#pragma unroll
+            for (int d = 2; d < TC_LAG; ++d) {
+                const int src = pos - d;
+                if (src >= 0) {
+                    const double *x = xring + (src % TC_LAG) * TBK;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double cf = g.live(src, pos, lane, w + 8 * j) ? tcf[d - 2][j] : 0.0;
+                        pr[j] = fma(cf, x[trans ? lane : w + 8 * j], pr[j]);
+                    }
+                }
             }
         }
-        double h = 0.0;
-        if (zlane && pos >= TC_LAG) h = chain_wait(sums + (size_t)pos * TBK + zslot, err, dead);
+        return trans ? chain_reduce8(pr, lane) : ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+    };
+    // The helper's sum for a position is asked for when a link begins and looked at when it ends (the answer takes
+    // a trip through memory); only if it has not been published by then does the wave wait.
+    auto ask_sum = [&](int pos) {
+        return (zlane && pos >= TC_LAG) ? __hip_atomic_load(sums + (size_t)pos * TBK + zslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    };
+    auto finish_terms = [&](int pos, double acc, double h, double zv) {
+        if (zlane && pos >= TC_LAG && __double_as_longlong(h) == -1ll) h = chain_wait(sums + (size_t)pos * TBK + zslot, err, dead);
         if (trans) {
-            const double tot = chain_reduce8(pr, lane);
-            if (zlane) rb[(pos & 1) * TBK + zslot] = zr - h - tot;
+            if (zlane) rb[(pos & 1) * TBK + zslot] = zv - h - acc;
         } else {
-            double acc = ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
-            if (zlane) acc -= zr - h;
+            if (zlane) acc -= zv - h;
             part[((pos & 1) * 8 + w) * TBK + lane] = acc;
         }
+    };
+    // A link whose blocks are all whole: the staged coefficients of position pos go to LDS and the registers are
+    // refilled for position pos + 1 one by one, so that the fetches stream while the arithmetic runs.
+    auto stage_and_load = [&](int pos) {
+        const int par = pos & 1;
+        const double *ri = rinvs + (pos & 3) * TBK;
+        const double *pc = block_ptr(pos + 1, pos + 1), *pb = block_ptr(pos + 1, pos + 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lu = w + 8 * j, k = trans ? lane : lu, l = trans ? lu : lane;
+            const double rinv = ri[k], cv = cst[j] * rinv;
+            Cs[(par * TBK + k) * TCS + l] = (k < l) ? cv : 0.0;              // source slot before destination slot
+            Bs[(par * TBK + k) * TCS + l] = bst[j] * rinv;
+            cst[j] = (k < l) ? pc[j * sj] : 0.0;
+            bst[j] = pb[j * sj];
+        }
+    };
+    // 1 / d from the hardware estimate and two correction steps (a full division is five times the instructions)
+    auto recip = [](double d) {
+        double y = __builtin_amdgcn_rcp(d);
+        y = fma(y, fma(-d, y, 1.0), y);
+        return fma(y, fma(-d, y, 1.0), y);
     };
     // The preparing waves keep their fetches for the next link in flight across the barrier: it orders LDS only.
     auto lds_barrier = [&]() {
@@ -431,7 +501,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
     }
     lds_barrier();
     if (wave < 8) {
-        do_terms(0);
+        finish_terms(0, do_terms(0), 0.0, zr);
         do_stage(0);
         load_stage(1);
         load_terms(1);
@@ -450,18 +520,20 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
                 const double *q = part + par * 8 * TBK + lane;
                 v = -(((q[0] + q[TBK]) + (q[2 * TBK] + q[3 * TBK])) + ((q[4 * TBK] + q[5 * TBK]) + (q[6 * TBK] + q[7 * TBK]))) - nacc;
             }
-            nacc = 0.0;
-            // the coefficients of a step are fetched from LDS eight steps ahead, into the registers the step just freed
-            double c8[8], b8[8];
+            // the coefficients of a step are fetched from LDS eight steps ahead, into the registers the step just freed;
+            // the coupling sums run in four independent parts beside the chain and are complete when it ends
+            double c8[8], b8[8], na[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 8; ++q) { c8[q] = C[q * TCS]; b8[q] = B[q * TCS]; }
 #pragma unroll
             for (int k = 0; k < TBK; ++k) {
                 const double yk = readlane_f64(v, k);
                 v = fma(-c8[k & 7], yk, v);
-                nacc = fma(b8[k & 7], yk, nacc);
+                na[k & 3] = fma(b8[k & 7], yk, na[k & 3]);
                 if (k + 8 < TBK) { c8[k & 7] = C[(k + 8) * TCS]; b8[k & 7] = B[(k + 8) * TCS]; }
             }
+            nacc = (na[0] + na[1]) + (na[2] + na[3]);
+            asm volatile("" : "+v"(nacc));                        // finished here, not at its use behind the barrier
             const int c = g.at(i, lane);
             const double x = (c >= 0) ? v * rinvs[(i & 3) * TBK + lane] : 0.0;
             xring[(i % TC_LAG) * TBK + lane] = x;
@@ -473,14 +545,22 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
     }
     for (int i = 0; i < g.nblk; ++i) {
         if (i + 1 < g.nblk) {
-            do_terms(i + 1);
-            do_stage(i + 1);
-            if (wave == 7) {
-                rinvs[((i + 2) & 3) * TBK + lane] = 1.0 / dgl;
-                dgl = diag_of(i + 3);
+            const bool whole = g.whole(i + 2 - TC_LAG, i + 3);
+            const double h = ask_sum(i + 1), zv = zr;             // zr: right-hand side entry of position i + 1, fetched a link ago
+            if (wave == 7) rinvs[((i + 2) & 3) * TBK + lane] = recip(dgl);       // before this link's fetches queue up behind it
+            const double acc = do_terms(i + 1);
+            if (whole) {
+                load_terms(i + 2);
+                stage_and_load(i + 1);
+            } else {
+                do_stage(i + 1);
             }
-            load_stage(i + 2);
-            load_terms(i + 2);
+            if (wave == 7) dgl = diag_of(i + 3);
+            if (!whole) {
+                load_stage(i + 2);
+                load_terms(i + 2);
+            }
+            finish_terms(i + 1, acc, h, zv);
         }
         lds_barrier();
     }
