@@ -357,6 +357,41 @@ __global__ void axpby_kernel(double a, const double *x, double b, const double *
 }
 
 // B(i, j) = A(n-1-i, n-1-j), or with `transposed` B(i, j) = A(n-1-j, n-1-i): both index reversals of a square matrix.
+// y = A x for a dense column-major n x n matrix, read once at memory speed: workgroup (rb, slab) takes rows
+// 64 rb ... 64 rb + 63 and every MV_SLABS-th group of four columns; a wave reads 64 consecutive rows of a column
+// (one 512-byte stretch), the four waves hold different columns.  part[slab][row] receives the slab's sum;
+// matvec_sum_kernel adds the slabs in a fixed order.
+constexpr int MV_SLABS = 16;
+__global__ __launch_bounds__(256) void matvec_slab_kernel(const double *A, int lda, int n, const double *x, double *part)
+{
+    __shared__ double red[4][64];
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, slab = blockIdx.y;
+    const int rr = min(r, n - 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = 4 * slab + q;
+    for (; c + 12 * MV_SLABS < n; c += 16 * MV_SLABS) {
+        const double v0 = A[(size_t)c * lda + rr], v1 = A[(size_t)(c + 4 * MV_SLABS) * lda + rr];
+        const double v2 = A[(size_t)(c + 8 * MV_SLABS) * lda + rr], v3 = A[(size_t)(c + 12 * MV_SLABS) * lda + rr];
+        a0 = fma(v0, x[c], a0); a1 = fma(v1, x[c + 4 * MV_SLABS], a1);
+        a2 = fma(v2, x[c + 8 * MV_SLABS], a2); a3 = fma(v3, x[c + 12 * MV_SLABS], a3);
+    }
+    for (; c < n; c += 4 * MV_SLABS) a0 = fma(A[(size_t)c * lda + rr], x[c], a0);
+    red[q][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 64 && r < n)
+        part[(size_t)slab * n + r] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void matvec_sum_kernel(const double *part, int n, double *y)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double acc = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < MV_SLABS; ++sl) acc += part[(size_t)sl * n + r];
+    y[r] = acc;
+}
+
 __global__ __launch_bounds__(256) void reverse_kernel(const double *A, int n, double *B, int transposed)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
@@ -481,10 +516,16 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
             }
         }
         // ---- src/fmin.hpp:54-105 ----
-        GemmDesc gv;                                   // Hp = Hcur * p
-        gv.M = n; gv.N = 1; gv.K = n; gv.transA = false; gv.transB = false;
-        gv.A = w.Hcur; gv.lda = n; gv.B = w.p; gv.ldb = n; gv.C = w.Hp; gv.ldc = n;
-        VSLAM_TRY(gemm_f64(ctx, gv));
+        if (n >= MV_SLABS) {                           // Hp = Hcur * p; the factor in w.U is spent, its memory takes the slab sums
+            hipLaunchKernelGGL(matvec_slab_kernel, dim3((n + 63) / 64, MV_SLABS), dim3(256), 0, s, w.Hcur, n, n, w.p, w.U);
+            hipLaunchKernelGGL(matvec_sum_kernel, dim3(nb), dim3(256), 0, s, w.U, n, w.Hp);
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+        } else {
+            GemmDesc gv;
+            gv.M = n; gv.N = 1; gv.K = n; gv.transA = false; gv.transB = false;
+            gv.A = w.Hcur; gv.lda = n; gv.B = w.p; gv.ldb = n; gv.C = w.Hp; gv.ldc = n;
+            VSLAM_TRY(gemm_f64(ctx, gv));
+        }
         hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n);
         VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hp, w.p, w.p));
         if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
