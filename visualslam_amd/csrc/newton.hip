@@ -48,8 +48,7 @@ __global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, in
         for (int j = 0; j < 16; ++j) U[lane * PLD + cb + j] = v[j];
     }
     __syncthreads();
-    if (wave == 0) potf2_lds(U, U + CB * PLD, jb, j0, info + blockIdx.y);
-    __syncthreads();
+    potf2_lds4(U, U + CB * PLD, jb, j0, info + blockIdx.y);
     potf_dinv16(U, U + CB * PLD, dinv + (size_t)blockIdx.y * stride_dinv);
     for (int c = wave; c < jb; c += 4)
         if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * PLD + c];
@@ -246,8 +245,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
                     if (R && n == g.N && m < g.N) R[g.r0g + m] = cold[i][j][r] - acc[i][j][r];    // a trailing block narrower than the tile
                 }
         __syncthreads();
-        if (wave == 0) potf2_lds(U, invd, jb, g.j0, g.info + b);
-        __syncthreads();
+        potf2_lds4(U, invd, jb, g.j0, g.info + b);
         potf_dinv16(U, invd, g.dinv + (size_t)b * g.stride_dinv);
         for (int c = wave; c < jb; c += 4)
             if (lane <= c) C[(size_t)c * g.lda + lane] = U[lane * PLD + c];

@@ -59,6 +59,62 @@ __device__ __attribute__((noinline)) void potf2_lds(double *U, double *invd, int
     }
 }
 
+// The same factorisation by the whole workgroup of four waves (every thread calls it; it holds its own
+// barriers).  The rows are still finished eight at a time by wave 0, but of the finished rows only the last eight
+// are applied by it (to the eight rows it factors next, in registers); the other three waves meanwhile apply the
+// same eight finished rows to all rows further down, in LDS.  Wave 0 then finds its next eight rows up to date
+// except for the group just finished -- its part of the work per group no longer grows with the group's position.
+__device__ __forceinline__ void potf2_lds4(double *U, double *invd, int jb, int j0, int *info)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool bad = false;
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            double acc[PR];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
+            if (kb > 0) {
+#pragma unroll
+                for (int l = kb - PR; l < kb; ++l) {
+                    const double own = U[l * PLD + lane];
+                    const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb);
+                    const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+                    acc[0] -= b0.x * own; acc[1] -= b0.y * own; acc[2] -= b1.x * own; acc[3] -= b1.y * own;
+                    acc[4] -= b2.x * own; acc[5] -= b2.y * own; acc[6] -= b3.x * own; acc[7] -= b3.y * own;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(acc[r], row);
+                if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
+                const double inv = rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : acc[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
+            }
+        } else if (kb > 0 && kb + PR < CB) {
+            // rows kb + 8 and beyond receive the rows kb - 8 ... kb - 1 (finished one barrier ago)
+            double own[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) own[q] = U[(kb - PR + q) * PLD + lane];
+            for (int r = kb + PR + (wave - 1); r < CB; r += 3) {
+                const double2 *bc = reinterpret_cast<const double2 *>(U + (kb - PR) * PLD + (r & ~1));
+                double a = U[r * PLD + lane];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const double2 b = bc[q * (PLD / 2)];
+                    a -= ((r & 1) ? b.y : b.x) * own[q];
+                }
+                U[r * PLD + lane] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Wave w of four: Yt = (U_ww)^-T for the w-th 16 x 16 diagonal sub-block of the factored block, written dense
 // (Yt[i][k] at 256 w + 16 i + k, lower triangular) to dinv.  Lane c < 16 owns column c of U_ww^-1 and
 // back-substitutes e_c with broadcast reads of U.  The row-panel solve multiplies by these instead of
