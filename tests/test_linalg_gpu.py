@@ -320,6 +320,23 @@ def test_triangular_vector_solve(ctx, n, trans):
     assert np.abs(res).max() <= 1e-11 * max(1.0, np.abs(z).max()) * np.sqrt(n)
 
 
+def test_triangular_vector_solve_many_calls_in_a_row(ctx):
+    """The solutions and helper sums a call publishes go to a fresh stretch of a ring that is refilled with the
+    not-ready pattern when it runs out: enough calls to go round it more than once, every result the same bits."""
+    import scipy.linalg as sla
+    n = 4000                                                # 2 * 63 * 64 values per call, a ring of 2^20: refilled every 130 calls
+    rng = np.random.default_rng(77)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + np.diag(1.0 + rng.random(n))
+    S = np.ascontiguousarray(U.T)
+    b = rng.standard_normal(n)
+    first = [_trsv(ctx, S, t, b) for t in (False, True)]
+    for t in (False, True):
+        assert rel_err(first[t], sla.solve_triangular(U, b, trans=1 if t else 0, lower=False)) <= 1e-11
+    for it in range(150):
+        for t in (False, True):
+            assert np.array_equal(_trsv(ctx, S, t, b), first[t]), (it, t)
+
+
 def _potrf(ctx, A, rhs=None):
     from visualslam_amd import _lib
     L = _lib.lib()

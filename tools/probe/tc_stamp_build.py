@@ -21,6 +21,7 @@ def rep(a, b):
     s = s.replace(a, b, 1)
 
 
+rep("        if (ctx->chain_used + need > VSLAM_CHAIN_SOL_DOUBLES) {", "        if (true) {   // stamps live beyond the call's own stretch: every call starts the ring afresh")
 rep("    double nacc = 0.0; ", "    long long *stamps = reinterpret_cast<long long *>(sol) + 16384;\n    double nacc = 0.0; ")
 rep("        for (int i = 0; i < g.nblk; ++i) {\n            const int par = i & 1;", "        for (int i = 0; i < g.nblk; ++i) {\n            if (lane == 0) stamps[i * 16 + 0] = wall_clock64();\n            const int par = i & 1;")
 rep("            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs", "            if (lane == 0 && v != 1234.5678) stamps[i * 16 + 1] = wall_clock64();\n            const int c = g.at(i, lane);\n            const double x = (c >= 0) ? v * rinvs")

@@ -15,7 +15,7 @@
 // A device-to-host copy staged in pinned memory, finished (pinned -> caller's buffer) after the stream drains.
 struct vslam_pending_copy { void *dst; const void *src; size_t width, height, dpitch; };
 
-constexpr int VSLAM_CHAIN_SOL_DOUBLES = 2 * 240 * 64;   // the chained triangular solve handles up to 240 blocks of 64 (solutions, then helper sums)
+constexpr size_t VSLAM_CHAIN_SOL_DOUBLES = (size_t)1 << 20;   // ring of solution blocks and helper sums of the chained triangular solves (one call: at most 2 * 240 * 64)
 
 struct vslam_ctx {
     int device = 0;
@@ -33,7 +33,9 @@ struct vslam_ctx {
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up
-    double *chain_sol = nullptr; // device: solution blocks of the chained triangular solve as its workgroups publish them
+    double *chain_sol = nullptr; // device: solution blocks of the chained triangular solve as its workgroups publish them.  A ring: every call takes
+                                 // a fresh stretch (filled with the not-ready pattern), the whole ring is refilled when it runs out
+    size_t chain_used = VSLAM_CHAIN_SOL_DOUBLES;   // "used up": the first call fills the ring, on the context's stream
     double *potf_dinv = nullptr; // device: per matrix of a blocked Cholesky, the inverses of the current diagonal block's 16 x 16 sub-blocks
     int potf_dinv_batch = 0;
     int *flags_host = nullptr;   // pinned mirror read by stream_finish

@@ -323,9 +323,10 @@ vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *inf
     return potrf_upper_batch_dev(ctx, A, n, lda, 0, 1, info, nullptr);
 }
 
-// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.
+// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.  With `info`,
+// out[3] carries *info instead (the factorisation's verdict travels to the host with the dot products).
 struct DotArgs { const double *a[4]; const double *b[4]; };
-__global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *out)
+__global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *out, const int *info)
 {
     __shared__ double red[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *ou
     if (tid < 4) {
         double sum = 0.0;
         for (int w = 0; w < 16; ++w) sum += red[tid][w];
-        out[tid] = sum;
+        out[tid] = (tid == 3 && info) ? (double)*info : sum;
     }
 }
 
@@ -452,11 +453,11 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
         DotArgs d;
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = nullptr; d.b[3] = nullptr;
-        hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots);
+        hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         VSLAM_TRY(d2h(ctx, hd, w.dots, 4 * 8));
-        VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
         VSLAM_TRY(stream_sync(ctx));
+        hinfo = (int)hd[3];
         return VSLAM_OK;
     };
     // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
@@ -464,12 +465,10 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
         if (lam != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(nb), dim3(256), 0, s, w.U, n, n, lam);
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.t, w.gcur, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, true, w.t, 0));      // t = U^-T g comes with the factor
+        // t = U^-T g comes with the factor; the strict lower triangle keeps stale values, which the solves never read
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, /*zero_lower=*/false, w.t, 0));
         ++factorisations;
-        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p));
-        hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, -1.0, w.p, 0.0, (const double *)nullptr, w.p, n);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
-        return VSLAM_OK;
+        return trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p, -1.0);
     };
     auto eval_at = [&](const double *x, double *f) -> vslam_status {
         if (x != c->x) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(c->x, x, (size_t)n * 8, hipMemcpyDeviceToDevice, s));

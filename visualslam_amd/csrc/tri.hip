@@ -123,6 +123,12 @@ vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, do
     return trtri_upper_batch_dev(ctx, S, n, ldS, 0, W, ldW, 0, 1, ws);
 }
 
+__global__ void scale_kernel(double *z, int n, double scale)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] *= scale;
+}
+
 // Vector solves with the upper-triangular S, one launch per 64-wide diagonal block: every
 // workgroup solves the block redundantly (one wave, the running right-hand side passed between
 // lanes), workgroup 0 stores that part of the solution, and each workgroup then removes the block's
@@ -215,7 +221,7 @@ constexpr int TC_LAG = 3;
 constexpr int TC_T = 576;                                     // eight preparing waves and the chain wave
 constexpr int TCS = TBK + 1;                                  // row stride of the staged blocks in LDS
 constexpr int TC_LDS_DOUBLES = 4 * TBK * TCS + 2 * TBK + 16 * TBK + 4 * TBK + TC_LAG * TBK;
-static_assert(2 * TC_MAX * TBK <= VSLAM_CHAIN_SOL_DOUBLES, "solution buffer of the context");
+static_assert((size_t)2 * TC_MAX * TBK <= VSLAM_CHAIN_SOL_DOUBLES, "solution buffer of the context");
 
 struct ChainGeo {
     const double *S; int n, ldS, trans, nblk;
@@ -295,7 +301,7 @@ __device__ __forceinline__ double chain_reduce8(const double (&v)[8], int lane)
 //   trans:  k = lane, l = w + 8 j        otherwise:  l = lane, k = w + 8 j
 // (interleaved over the waves: the triangular diagonal block then gives every wave the same share).
 template <bool trans>
-__global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, double *z, double *sol, int *err)
+__global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, const double *rhs, double scale, double *z, double *sol, int *err)
 {
     extern __shared__ double tc_lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, w = wave & 7;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
                 for (int j = 0; j < 8; ++j) tcf[d - 2][j] = g.raw(pos - d, pos, lane, w + 8 * j);
         }
         const int c = g.at(pos, zslot);
-        zr = (zlane && c >= 0) ? z[c] : 0.0;
+        zr = (zlane && c >= 0) ? rhs[c] : 0.0;
     };
     auto do_stage = [&](int pos) {
         const int par = pos & 1;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             const double x = (c >= 0) ? v * rinvs[(i & 3) * TBK + lane] : 0.0;
             xring[(i % TC_LAG) * TBK + lane] = x;
             __hip_atomic_store(&sol[(size_t)i * TBK + lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c >= 0) z[c] = x;
+            if (c >= 0) z[c] = scale * x;
             lds_barrier();
         }
         return;
@@ -566,22 +572,27 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
     }
 }
 
-vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z)
+vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z, double scale)
 {
     hipStream_t s = ctx->stream;
-    if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     const int nblk = (n + TBK - 1) / TBK;
     if (nblk > 1 && nblk <= TC_MAX) {
-        const size_t lds = (size_t)TC_LDS_DOUBLES * 8;
+        const size_t lds = (size_t)TC_LDS_DOUBLES * 8, need = (size_t)2 * nblk * TBK;
         VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, (size_t)2 * nblk * TBK * 8, s));
+        if (ctx->chain_used + need > VSLAM_CHAIN_SOL_DOUBLES) {          // ring used up: every entry back to "not ready", behind the calls that used it
+            VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, VSLAM_CHAIN_SOL_DOUBLES * 8, s));
+            ctx->chain_used = 0;
+        }
+        double *sol = ctx->chain_sol + ctx->chain_used;
+        ctx->chain_used += need;
         const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
-        if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, z, ctx->chain_sol, ctx->flags);
-        else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, z, ctx->chain_sol, ctx->flags);
+        if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags);
+        else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     }
+    if (z != b) VSLAM_HIP_TRY(ctx, hipMemcpyAsync(z, b, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     for (int step = 0; step < nblk; ++step) {
         const int blk = trans ? step : nblk - 1 - step;
         const int i0 = blk * TBK, ib = (n - i0) < TBK ? (n - i0) : TBK;
@@ -589,6 +600,7 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         const int grid = rest > 0 ? (rest + 255) / 256 : 1;
         hipLaunchKernelGGL(trsv_step_kernel, dim3(grid), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, i0, ib, z);
     }
+    if (scale != 1.0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z, n, scale);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
