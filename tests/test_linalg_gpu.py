@@ -337,6 +337,33 @@ def test_triangular_vector_solve_many_calls_in_a_row(ctx):
             assert np.array_equal(_trsv(ctx, S, t, b), first[t]), (it, t)
 
 
+@pytest.mark.parametrize("n", [65, 128, 200, 462, 1000, 1024])
+@pytest.mark.parametrize("trans", [False, True])
+def test_triangular_vector_solve_bank(ctx, n, trans):
+    """One workgroup per matrix: every solution block stays in LDS, the far contributions are added up a link early.
+    Masked matrices keep their output; the scale factor reaches the result only."""
+    import scipy.linalg as sla
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5 * n + int(trans))
+    B = 7
+    U = np.triu(rng.standard_normal((B, n, n))) / np.sqrt(n) + np.eye(n) * ((1.0 + rng.random((B, n, 1))) * rng.choice([-1.0, 1.0], (B, n, 1)))
+    S = np.ascontiguousarray(np.transpose(U + np.tril(rng.standard_normal((B, n, n)), -1), (0, 2, 1)))
+    b = rng.standard_normal((B, n))
+    z = np.full((B, n), 123.0)
+    active = np.array([1, 1, 0, 1, 1, 1, 0], dtype=np.int32)
+    fn = L.vslam_debug_trsv_bank
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    assert fn(ctx.ptr, S.ctypes.data, n, B, int(trans), b.ctypes.data, z.ctypes.data, -2.0, active.ctypes.data) == 0, L.vslam_last_error(ctx.ptr)
+    for m in range(B):
+        if not active[m]:
+            assert (z[m] == 123.0).all()
+            continue
+        z0 = -2.0 * sla.solve_triangular(U[m], b[m], trans=1 if trans else 0, lower=False)
+        assert rel_err(z[m], z0) <= 1e-11, m
+
+
 def _potrf(ctx, A, rhs=None):
     from visualslam_amd import _lib
     L = _lib.lib()

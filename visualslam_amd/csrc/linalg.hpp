@@ -81,6 +81,11 @@ vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int l
 // Solves S^T x = b (trans = true) or S x = b (trans = false) for one vector, S upper triangular (the strict lower
 // triangle is never read); z = scale * x.  b and z may be the same vector.
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z, double scale = 1.0);
+// The same for a bank of matrices strideS apart (vectors n apart; active[m] == 0 skips matrix m; active may be null),
+// one workgroup per matrix; only for sizes trsv_upper_bank_fits accepts.
+bool trsv_upper_bank_fits(int n);
+vslam_status trsv_upper_bank_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, bool trans, const double *rhs, double *z,
+                                 double scale, const int *active, int count);
 
 // Batched point-landmark log-likelihood (point_loglik.hip), all pointers device, strides in elements;
 // active (optional, device): instances whose entry is 0 are skipped.

@@ -318,8 +318,12 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     std::vector<double> f(B, 0.0), fn(B, 0.0);
     std::vector<std::vector<int>> ahead(B);                     // slots holding the filter's next subproblems, nearest first
 
+    // One workgroup per matrix either way: the chain form of tri.hip where its blocks fit LDS (VSLAM_BANK_TRSV_OLD=1 keeps
+    // the older kernel for A/B runs), bk_trsv_kernel otherwise.
+    const bool chain_trsv = trsv_upper_bank_fits(n) && !getenv("VSLAM_BANK_TRSV_OLD");
     auto trsv = [&](const double *M, bool trans, const double *rhs, double *out, double scale, const int *mask, int count) {
-        hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
+        if (chain_trsv) (void)trsv_upper_bank_dev(ctx, M, n, n, nn, trans, rhs, out, scale, mask, count);
+        else hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
     };
     // a mask over the filters, or over all slots; the device array always holds Bt words
     auto send_mask = [&](const std::vector<int> &h) -> vslam_status {

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
 // raises *err and lets every wave run to the end.
 constexpr int TC_MAX = 240;
 constexpr int TC_LAG = 3;
+constexpr int TC_BANK_BLOCKS = 16;                            // a bank matrix has at most this many blocks (its solution stays in LDS)
 constexpr int TC_T = 576;                                     // eight preparing waves and the chain wave
 constexpr int TCS = TBK + 1;                                  // row stride of the staged blocks in LDS
 constexpr int TC_LDS_DOUBLES = 4 * TBK * TCS + 2 * TBK + 16 * TBK + 4 * TBK + TC_LAG * TBK;
@@ -300,17 +301,27 @@ __device__ __forceinline__ double chain_reduce8(const double (&v)[8], int lane)
 // equation of slot l, with the lanes along whichever of the two is contiguous in memory:
 //   trans:  k = lane, l = w + 8 j        otherwise:  l = lane, k = w + 8 j
 // (interleaved over the waves: the triangular diagonal block then gives every wave the same share).
-template <bool trans>
-__global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, const double *rhs, double scale, double *z, double *sol, int *err)
+//
+// BANK: one workgroup per matrix of a bank (blockIdx.y; matrices strideS apart, right-hand sides and results n apart,
+// `active` masks matrices out) and no helpers: all solution blocks stay in LDS, and what a helper would supply --
+// the contributions of the positions three or more back -- the preparing waves add up themselves one link early
+// (the blocks it needs are final by then) and carry, unreduced, in registers into the link that uses it.
+template <bool trans, bool BANK>
+__global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, const double *rhs, double scale, double *z, double *sol, int *err,
+                                                          size_t strideS, const int *active)
 {
     extern __shared__ double tc_lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, w = wave & 7;
+    if (BANK) {
+        if (active && !active[blockIdx.y]) return;
+        S += (size_t)blockIdx.y * strideS; rhs += (size_t)blockIdx.y * n; z += (size_t)blockIdx.y * n;
+    }
     ChainGeo g{S, n, ldS, trans, (n + TBK - 1) / TBK};
     double *sums = sol + (size_t)g.nblk * TBK;                   // helper sums, one block of 64 per position
     bool dead = false;
     const int jl = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);     // whose total chain_reduce8 leaves here
 
-    if (blockIdx.x > 0) {
+    if (!BANK && blockIdx.x > 0) {
         // helper: everything at least TC_LAG positions back, for position pos
         const int pos = TC_LAG - 1 + (int)blockIdx.x;
         double *part = tc_lds;                                   // [8][64]
@@ -358,7 +369,8 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
     double *rb = Bs + 2 * TBK * TCS;              // [2][64] trans: right-hand side of a position without its newest contribution
     double *part = rb + 2 * TBK;                  // [2][8][64] otherwise: the same in eight parts, negated
     double *rinvs = part + 2 * 8 * TBK;           // [4][64] reciprocal pivots
-    double *xring = rinvs + 4 * TBK;              // [TC_LAG][64] the latest solution blocks
+    double *xring = rinvs + 4 * TBK;              // [TC_LAG][64] the latest solution blocks (BANK: [nblk][64], all of them)
+    auto xslot = [&](int pos) { return BANK ? pos : pos % TC_LAG; };
 
     double cst[8], bst[8], tcf[TC_LAG - 2][8], zr = 0.0, dgl = 1.0;
     const bool zlane = trans ? (lane & 7) == 0 : w == 0;          // lanes that finish a right-hand side entry
@@ -426,14 +438,15 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             }
         }
     };
+    double carry[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};    // BANK: the far contributions to the position of the next link
     auto do_terms = [&](int pos) -> double {
         double pr[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pr[j] = 0.0;
+        for (int j = 0; j < 8; ++j) pr[j] = BANK ? carry[j] : 0.0;
         if (g.whole(pos - (TC_LAG - 1), pos)) {
 #pragma unroll
             for (int d = 2; d < TC_LAG; ++d) {
-                const double *x = xring + ((pos - d) % TC_LAG) * TBK;
+                const double *x = xring + xslot(pos - d) * TBK;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pr[j] = fma(tcf[d - 2][j], x[trans ? lane : w + 8 * j], pr[j]);
             }
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             for (int d = 2; d < TC_LAG; ++d) {
                 const int src = pos - d;
                 if (src >= 0) {
-                    const double *x = xring + (src % TC_LAG) * TBK;
+                    const double *x = xring + xslot(src) * TBK;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const double cf = g.live(src, pos, lane, w + 8 * j) ? tcf[d - 2][j] : 0.0;
@@ -456,10 +469,10 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
     // The helper's sum for a position is asked for when a link begins and looked at when it ends (the answer takes
     // a trip through memory); only if it has not been published by then does the wave wait.
     auto ask_sum = [&](int pos) {
-        return (zlane && pos >= TC_LAG) ? __hip_atomic_load(sums + (size_t)pos * TBK + zslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        return (!BANK && zlane && pos >= TC_LAG) ? __hip_atomic_load(sums + (size_t)pos * TBK + zslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     };
     auto finish_terms = [&](int pos, double acc, double h, double zv) {
-        if (zlane && pos >= TC_LAG && __double_as_longlong(h) == -1ll) h = chain_wait(sums + (size_t)pos * TBK + zslot, err, dead);
+        if (!BANK && zlane && pos >= TC_LAG && __double_as_longlong(h) == -1ll) h = chain_wait(sums + (size_t)pos * TBK + zslot, err, dead);
         if (trans) {
             if (zlane) rb[(pos & 1) * TBK + zslot] = zv - h - acc;
         } else {
@@ -481,6 +494,27 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             Bs[(par * TBK + k) * TCS + l] = bst[j] * rinv;
             cst[j] = (k < l) ? pc[j * sj] : 0.0;
             bst[j] = pb[j * sj];
+        }
+    };
+    // BANK: carry <- contributions of the positions 0 ... pos - TC_LAG to position pos (all final when this is called)
+    auto far_terms = [&](int pos) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) carry[j] = 0.0;
+        for (int src = 0; src + TC_LAG <= pos; ++src) {
+            const double *x = xring + src * TBK;
+            double cf[8];
+            if (g.whole(src, src) && g.whole(pos, pos)) {
+                const double *pt = block_ptr(src, pos);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cf[j] = pt[j * sj];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cf[j] = g.raw(src, pos, lane, w + 8 * j);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cf[j] = g.live(src, pos, lane, w + 8 * j) ? cf[j] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) carry[j] = fma(cf[j], x[trans ? lane : w + 8 * j], carry[j]);
         }
     };
     // 1 / d from the hardware estimate and two correction steps (a full division is five times the instructions)
@@ -542,8 +576,8 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             asm volatile("" : "+v"(nacc));                        // finished here, not at its use behind the barrier
             const int c = g.at(i, lane);
             const double x = (c >= 0) ? v * rinvs[(i & 3) * TBK + lane] : 0.0;
-            xring[(i % TC_LAG) * TBK + lane] = x;
-            __hip_atomic_store(&sol[(size_t)i * TBK + lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xring[xslot(i) * TBK + lane] = x;
+            if (!BANK) __hip_atomic_store(&sol[(size_t)i * TBK + lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c >= 0) z[c] = scale * x;
             lds_barrier();
         }
@@ -567,6 +601,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
                 load_terms(i + 2);
             }
             finish_terms(i + 1, acc, h, zv);
+            if (BANK && i + 2 < g.nblk) far_terms(i + 2);
         }
         lds_barrier();
     }
@@ -578,8 +613,8 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
     const int nblk = (n + TBK - 1) / TBK;
     if (nblk > 1 && nblk <= TC_MAX) {
         const size_t lds = (size_t)TC_LDS_DOUBLES * 8, need = (size_t)2 * nblk * TBK;
-        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (ctx->chain_used + need > VSLAM_CHAIN_SOL_DOUBLES) {          // ring used up: every entry back to "not ready", behind the calls that used it
             VSLAM_HIP_TRY(ctx, hipMemsetAsync(ctx->chain_sol, 0xff, VSLAM_CHAIN_SOL_DOUBLES * 8, s));
             ctx->chain_used = 0;
@@ -587,8 +622,8 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         double *sol = ctx->chain_sol + ctx->chain_used;
         ctx->chain_used += need;
         const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
-        if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags);
-        else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags);
+        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr);
+        else hipLaunchKernelGGL((trsv_chain_kernel<false, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     }
@@ -601,6 +636,31 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         hipLaunchKernelGGL(trsv_step_kernel, dim3(grid), dim3(256), 0, s, S, n, ldS, trans ? 1 : 0, i0, ib, z);
     }
     if (scale != 1.0) hipLaunchKernelGGL(scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z, n, scale);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
+// The same solves for a bank: matrix m at S + m * strideS, right-hand side and result at rhs / z + m * n (they may be
+// the same vectors), matrices with active[m] == 0 skipped (active may be null).  False when the size is outside what
+// the one-workgroup-per-matrix kernel holds in LDS (the caller then takes its own route).
+bool trsv_upper_bank_fits(int n) { return n > TBK && (n + TBK - 1) / TBK <= TC_BANK_BLOCKS; }
+vslam_status trsv_upper_bank_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, bool trans, const double *rhs, double *z,
+                                 double scale, const int *active, int count)
+{
+    if (!trsv_upper_bank_fits(n)) return fail(ctx, VSLAM_ERR_SHAPE, "bank triangular solve: n = %d is outside 65 ... %d", n, TC_BANK_BLOCKS * TBK);
+    const int nblk = (n + TBK - 1) / TBK;
+    const size_t lds = (size_t)(TC_LDS_DOUBLES - TC_LAG * TBK + nblk * TBK) * 8;
+    hipStream_t s = ctx->stream;
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int m0 = 0; m0 < count; m0 += 65535) {
+        const int cnt = count - m0 < 65535 ? count - m0 : 65535;
+        const double *Sm = S + (size_t)m0 * strideS, *rm = rhs + (size_t)m0 * n;
+        double *zm = z + (size_t)m0 * n;
+        const int *am = active ? active + m0 : nullptr;
+        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am);
+        else hipLaunchKernelGGL((trsv_chain_kernel<false, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am);
+    }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -642,5 +702,28 @@ extern "C" vslam_status vslam_debug_trsv(vslam_ctx *ctx, const double *S, int n,
     VSLAM_TRY(h2d(ctx, db, b, (size_t)n * 8));
     VSLAM_TRY(trsv_upper_dev(ctx, dS, n, n, trans != 0, db, dz));
     VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));
+    return stream_finish(ctx);
+}
+
+// Test hook (not part of the public header): the same for `batch` matrices held one after the other ([batch][n][n]
+// column-major, right-hand sides and results [batch][n]); active (host, may be null) masks matrices out, whose results
+// are left as they were.
+extern "C" vslam_status vslam_debug_trsv_bank(vslam_ctx *ctx, const double *S, int n, int batch, int trans, const double *b, double *z, double scale,
+                                              const int *active)
+{
+    using namespace vslam;
+    if (!ctx || !S || !b || !z || n < 1 || batch < 1) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    VSLAM_TRY(ws_reserve(ctx, Arena::pad(nn * batch * 8) + 2 * Arena::pad((size_t)n * batch * 8) + Arena::pad((size_t)batch * sizeof(int))));
+    Arena ar(ctx->ws);
+    double *dS = ar.take<double>(nn * batch), *db = ar.take<double>((size_t)n * batch), *dz = ar.take<double>((size_t)n * batch);
+    int *da = ar.take<int>(batch);
+    VSLAM_TRY(h2d(ctx, dS, S, nn * batch * 8));
+    VSLAM_TRY(h2d(ctx, db, b, (size_t)n * batch * 8));
+    VSLAM_TRY(h2d(ctx, dz, z, (size_t)n * batch * 8));
+    if (active) VSLAM_TRY(h2d(ctx, da, active, (size_t)batch * sizeof(int)));
+    VSLAM_TRY(trsv_upper_bank_dev(ctx, dS, n, n, nn, trans != 0, db, dz, scale, active ? da : nullptr, batch));
+    VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * batch * 8));
     return stream_finish(ctx);
 }
