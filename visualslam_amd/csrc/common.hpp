@@ -122,4 +122,17 @@ struct CamK {
 };
 vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *out);
 
+// Which instance of a bank row y of a grid works on: every row its own (sel null), the rows whose mask word is
+// non-zero (listed == 0: the grid covers all instances, the others leave at once) or the y-th entry of a list of
+// instances (listed != 0: the grid covers the list only -- a launch over a thousand instances of which a handful
+// take part otherwise spends its time dispatching workgroups that leave).  -1: nothing to do.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int instance_of(const int *sel, int listed, int y)
+{
+    if (!sel) return y;
+    if (listed) return sel[y];
+    return sel[y] ? y : -1;
+}
+#endif
+
 }  // namespace vslam

@@ -85,7 +85,7 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
 // one workgroup per matrix; only for sizes trsv_upper_bank_fits accepts.
 bool trsv_upper_bank_fits(int n);
 vslam_status trsv_upper_bank_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, bool trans, const double *rhs, double *z,
-                                 double scale, const int *active, int count);
+                                 double scale, const int *active, int count, bool listed = false);
 
 // Batched point-landmark log-likelihood (point_loglik.hip), all pointers device, strides in elements;
 // active (optional, device): instances whose entry is 0 are skipped.
@@ -127,7 +127,8 @@ vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *inf
 // rhs (optional, one n-vector per matrix, stride_rhs apart): on return U^-T rhs -- the forward substitution rides
 // along with the factorisation as one more column of the row-panel solves and trailing updates.
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower = true, double *rhs = nullptr, size_t stride_rhs = 0);
+                                   bool zero_lower = true, double *rhs = nullptr, size_t stride_rhs = 0, bool listed = false);
+// listed: `active` holds `batch` matrix indices (the launches cover those matrices only) instead of a mask over `batch` matrices.
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
                                 int *status_out);

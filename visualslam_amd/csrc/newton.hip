@@ -32,13 +32,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // factor back.  Only the upper triangle is read and written.  Used for the first block of a factorisation and for
 // trailing matrices too small for the GEMM epilogue; every other diagonal block is factored by the workgroup of
 // the trailing update that produced it (gemm.hip).
-__global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info, size_t strideA, const int *active,
+__global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, int j0, int jb, int *info, size_t strideA, const int *active, int listed,
                                                            double *dinv, size_t stride_dinv)
 {
     __shared__ __align__(16) double U[POTF_LDS_DOUBLES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (active && !active[blockIdx.y]) return;                    // instance blockIdx.y of a batch (stride strideA, one info word each)
-    A += (size_t)blockIdx.y * strideA;
+    const int b = instance_of(active, listed, blockIdx.y);        // instance of a batch (stride strideA, one info word each)
+    if (b < 0) return;
+    A += (size_t)b * strideA;
     for (int cb = 16 * wave; cb < 16 * wave + 16; cb += 16) {      // lane = row: coalesced column reads, 16 in flight
         double v[16];
 #pragma unroll
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, in
         for (int j = 0; j < 16; ++j) U[lane * PLD + cb + j] = v[j];
     }
     __syncthreads();
-    potf2_lds4(U, U + CB * PLD, jb, j0, info + blockIdx.y);
+    potf2_lds4(U, U + CB * PLD, jb, j0, info + b);
     potf_dinv16(U, U + CB * PLD, dinv + (size_t)blockIdx.y * stride_dinv);
     for (int c = wave; c < jb; c += 4)
         if (lane <= c) A[(size_t)(j0 + c) * lda + j0 + lane] = U[lane * PLD + c];
@@ -63,22 +64,23 @@ __global__ __launch_bounds__(256) void potf2_upper_kernel(double *A, int lda, in
 // block (potf_dinv16), U_ij from the factored block itself.
 constexpr int TLD = 17;          // row stride of the 16 x 16 inverses in LDS
 // A right-hand side vector (R, one per matrix) rides along as column n: when the factorisation ends it holds U^-T r.
-__global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active,
+__global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int n, int j0, size_t strideA, const int *active, int listed,
                                                           const double *dinv, size_t stride_dinv, double *R, size_t strideR)
 {
     __shared__ __align__(16) double U[CB * PLD];                   // U[l][j] at l * PLD + j (upper triangle meaningful)
     __shared__ double Yt[4 * 16 * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
-    if (active && !active[blockIdx.y]) return;
-    A += (size_t)blockIdx.y * strideA;
-    dinv += (size_t)blockIdx.y * stride_dinv;
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
+    A += (size_t)b * strideA;
+    dinv += (size_t)blockIdx.y * stride_dinv;                      // scratch of the grid row, as the kernels before and after use it
     const int jb = min(CB, n - j0);                                // the last block row may be short (then only R is to its right)
     const int c0 = j0 + jb + blockIdx.x * CB;
     const int col = c0 + 16 * wave + l15;
     const bool cok = col < n + (R ? 1 : 0);
     // right-hand side: block bi, register q <-> row 16 bi + 4 q + kr of this lane's column
     double4_t Rb[4];
-    double *colp = (cok && col == n) ? R + (size_t)blockIdx.y * strideR + j0 : A + (size_t)(cok ? col : min(c0, n - 1)) * lda + j0;
+    double *colp = (cok && col == n) ? R + (size_t)b * strideR + j0 : A + (size_t)(cok ? col : min(c0, n - 1)) * lda + j0;
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
@@ -127,7 +129,7 @@ struct CholUpdArgs {
     double *C;                     // element (0, 0) of the trailing block
     int N, K, lda;
     size_t strideA;
-    const int *active;
+    const int *active; int listed;
     double *dinv; size_t stride_dinv; int *info; int j0;
     double *R; size_t strideR;     // optional right-hand side riding along as column N of the trailing block:
     int k0g, r0g;                  //   its entries beside P start at R[k0g], those beside C at R[r0g]
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
     static_assert(2 * CB * ULD <= POTF_LDS_DOUBLES, "operand chunks fit");
     double *const Pm = Ps, *const Pn = Ps + CB * ULD;                 // [column of the tile][row of the chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
-    const int b = blockIdx.y;
-    if (g.active && !g.active[b]) return;
+    const int b = instance_of(g.active, g.listed, blockIdx.y);
+    if (b < 0) return;
     const int T = (g.N + CB - 1) / CB, tri = T * (T + 1) / 2;
     int tile_m, tile_n;
     if ((int)blockIdx.x < tri) upper_tile(blockIdx.x, &tile_m, &tile_n);
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
                 }
         __syncthreads();
         potf2_lds4(U, invd, jb, g.j0, g.info + b);
-        potf_dinv16(U, invd, g.dinv + (size_t)b * g.stride_dinv);
+        potf_dinv16(U, invd, g.dinv + (size_t)blockIdx.y * g.stride_dinv);       // scratch of the grid row (the row panel kernel reads it there)
         for (int c = wave; c < jb; c += 4)
             if (lane <= c) C[(size_t)c * g.lda + lane] = U[lane * PLD + c];
         return;
@@ -269,10 +271,11 @@ __global__ void add_diag_kernel(double *A, int lda, int n, double lam)
 }
 
 // strict lower triangle := 0 for matrix blockIdx.y of a batch (grid-stride over the n*n elements)
-__global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA, const int *active)
+__global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA, const int *active, int listed)
 {
-    if (active && !active[blockIdx.y]) return;
-    double *Ab = A + (size_t)blockIdx.y * strideA;
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
+    double *Ab = A + (size_t)b * strideA;
     const size_t nn = (size_t)n * n, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nn; idx += stride) {
         const int c = (int)(idx / n), r = (int)(idx - (size_t)c * n);
@@ -284,9 +287,10 @@ __global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA
 // triangles are overwritten: U above, zeros below).  info: one device word per matrix, 0 on entry.
 // active (device, may be null): matrices whose entry is 0 are left alone (except for the zeroing of
 // their strict lower triangle).  zero_lower = false leaves the strict lower triangle as it is (a caller
-// that only ever reads the upper triangle of the factor saves the pass).
+// that only ever reads the upper triangle of the factor saves the pass).  listed: `active` is a list of `batch`
+// matrix indices instead of a mask over `batch` matrices (info, rhs and A are still indexed by matrix).
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower, double *rhs, size_t stride_rhs)
+                                   bool zero_lower, double *rhs, size_t stride_rhs, bool listed)
 {
     hipStream_t s = ctx->stream;
     VSLAM_TRY(potf_dinv_reserve(ctx, batch));
@@ -295,16 +299,16 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
     bool factored = false;                            // the diagonal block of this step was factored by the previous update
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
-        if (!factored) hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(256), 0, s, A, lda, j0, jb, info, strideA, active, dinv, (size_t)1024);
+        if (!factored) hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(256), 0, s, A, lda, j0, jb, info, strideA, active, listed ? 1 : 0, dinv, (size_t)1024);
         const int rest = n - j0 - jb;
         if (rest + extra <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, dinv, (size_t)1024,
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, listed ? 1 : 0, dinv, (size_t)1024,
                            rhs, stride_rhs);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (rest <= 0) break;
         CholUpdArgs g;                                // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
         g.P = A + (size_t)(j0 + jb) * lda + j0; g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.N = rest; g.K = jb; g.lda = lda;
-        g.strideA = strideA; g.active = active; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
+        g.strideA = strideA; g.active = active; g.listed = listed ? 1 : 0; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
         g.R = rhs; g.strideR = stride_rhs; g.k0g = j0; g.r0g = j0 + jb;
         const int T = (rest + CB - 1) / CB, TC = (rest + extra + CB - 1) / CB;
         hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2 + (TC > T ? T : 0), batch), dim3(256), 0, s, g);
@@ -313,7 +317,7 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
     }
     if (!zero_lower) return VSLAM_OK;
     const size_t zblocks = ((size_t)n * n + 4095) / 4096;
-    hipLaunchKernelGGL(zero_below_diag_kernel, dim3((unsigned)(zblocks < 1024 ? zblocks : 1024), batch), dim3(256), 0, s, A, lda, n, strideA, active);
+    hipLaunchKernelGGL(zero_below_diag_kernel, dim3((unsigned)(zblocks < 1024 ? zblocks : 1024), batch), dim3(256), 0, s, A, lda, n, strideA, active, listed ? 1 : 0);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }

@@ -153,11 +153,34 @@ __global__ void bk_axpby_kernel(double a, const double *x, double c, const doubl
     out[e] = a * x[e] + (y ? c * y[e] : 0.0);
 }
 
-// dst[b] = src[b] (count doubles per instance), active instances only
-__global__ void bk_copy_kernel(double *dst, const double *src, size_t count, const int *active)
+// y[b] = H[b] x[b] for the n x n column-major matrices of the selected instances (ld n, matrices n * n apart, vectors
+// n apart): workgroup (rb, row of the grid) takes rows 64 rb ... 64 rb + 63, its four waves every fourth column; a wave
+// reads 64 consecutive rows of a column.  Fixed summation order.
+__global__ __launch_bounds__(256) void bk_matvec_kernel(const double *H, int n, const double *x, double *y, const int *active, int listed)
 {
-    const int b = blockIdx.y;
-    if (active && !active[b]) return;
+    __shared__ double red[4][64];
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
+    const double *Hb = H + (size_t)b * n * n, *xb = x + (size_t)b * n;
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, rr = min(r, n - 1);
+    double a0 = 0.0, a1 = 0.0;
+    int c = q;
+    for (; c + 4 < n; c += 8) {
+        const double v0 = Hb[(size_t)c * n + rr], v1 = Hb[(size_t)(c + 4) * n + rr];
+        a0 = fma(v0, xb[c], a0); a1 = fma(v1, xb[c + 4], a1);
+    }
+    if (c < n) a0 = fma(Hb[(size_t)c * n + rr], xb[c], a0);
+    red[q][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 64 && r < n)
+        y[(size_t)b * n + r] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dst[b] = src[b] (count doubles per instance), active instances only
+__global__ void bk_copy_kernel(double *dst, const double *src, size_t count, const int *active, int listed = 0)
+{
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
     const size_t base = (size_t)b * count, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[base + i] = src[base + i];
 }
@@ -173,10 +196,10 @@ __global__ void bk_gather_kernel(double *dst, const double *src, size_t count, c
 
 // upper triangle of U[b] = that of H[b] + lam[b] I  (n x n, ld n), active instances only; the factorisation and the
 // solves that follow never touch the strict lower triangle.  One column per blockIdx.x step.
-__global__ void bk_shifted_copy_kernel(double *U, const double *H, int n, const double *lam, const int *active)
+__global__ void bk_shifted_copy_kernel(double *U, const double *H, int n, const double *lam, const int *active, int listed)
 {
-    const int b = blockIdx.y;
-    if (active && !active[b]) return;
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
     const size_t base = (size_t)b * n * n;
     const double l = lam[b];
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
@@ -325,11 +348,18 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         if (chain_trsv) (void)trsv_upper_bank_dev(ctx, M, n, n, nn, trans, rhs, out, scale, mask, count);
         else hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
     };
-    // a mask over the filters, or over all slots; the device array always holds Bt words
+    // A mask over the filters, or over all slots; the device array always holds Bt mask words and, behind them, the
+    // slots of the mask as a list (nlisted of them): the factorisations and their solves launch over the list, so a
+    // step in which a handful of slots take part does not dispatch workgroups for all of them.
+    std::vector<int> sel((size_t)2 * Bt, 0);
+    int nlisted = 0;
+    int *const listv = w.active + Bt;
     auto send_mask = [&](const std::vector<int> &h) -> vslam_status {
-        VSLAM_TRY(h2d(ctx, w.active, h.data(), h.size() * sizeof(int)));
-        if ((int)h.size() < Bt) VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.active + h.size(), 0, (Bt - h.size()) * sizeof(int), s));
-        return VSLAM_OK;
+        std::fill(sel.begin(), sel.end(), 0);
+        nlisted = 0;
+        for (size_t i = 0; i < h.size(); ++i)
+            if (h[i]) { sel[i] = 1; sel[(size_t)Bt + nlisted++] = (int)i; }
+        return h2d(ctx, w.active, sel.data(), sel.size() * sizeof(int));
     };
     auto any = [&](const std::vector<int> &h) { return std::any_of(h.begin(), h.end(), [](int v) { return v != 0; }); };
     // results of bk_dots_kernel and the factorisation flags of all slots
@@ -345,11 +375,16 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     // for the slots of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&]() -> vslam_status {
         VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)Bt * 8));
-        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), Bt), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, w.active);
+        if (nlisted == 0) return VSLAM_OK;
+        const bool by_list = chain_trsv && nlisted < Bt;            // launches over the list of slots (the older solve kernel takes masks only)
+        const int *selp = by_list ? listv : w.active;
+        const int rows = by_list ? nlisted : Bt, lf = by_list ? 1 : 0;
+        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), rows), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, selp, lf);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, Bt), dim3(256), 0, s, w.t, w.gcur, (size_t)n, w.active);
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, Bt, w.info, w.active, /*zero_lower=*/false, w.t, (size_t)n));   // t = U^-T g comes with the factor
-        trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt);
+        hipLaunchKernelGGL(bk_copy_kernel, dim3(1, rows), dim3(256), 0, s, w.t, w.gcur, (size_t)n, selp, lf);
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, rows, w.info, selp, /*zero_lower=*/false, w.t, (size_t)n, by_list));   // t = U^-T g comes with the factor
+        if (by_list) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, false, w.t, w.p, -1.0, selp, rows, true));
+        else trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     };
@@ -458,7 +493,8 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         for (int sl = 0; sl < Bt; ++sl) m[sl] = trs[sl] && std::sqrt(hd[(size_t)4 * sl]) > Delta[sl];
         for (int kk = 0; kk < 20 && any(m); ++kk) {
             VSLAM_TRY(send_mask(m));
-            trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt);
+            if (chain_trsv && nlisted < Bt) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, true, w.p, w.q, 1.0, listv, nlisted, true));
+            else trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt);
             VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
             drop_failed(m);
             std::vector<int> stop(Bt, 0);
@@ -481,10 +517,10 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         }
         // ---- src/fmin.hpp:54-105: predicted decrease and the trial point of every slot ----
         VSLAM_TRY(send_mask(trs));
-        GemmDesc gv;                                   // Hpv = Hcur * p
-        gv.M = n; gv.N = 1; gv.K = n; gv.transA = false; gv.transB = false;
-        gv.A = w.Hcur; gv.lda = n; gv.strideA = nn; gv.B = w.p; gv.ldb = n; gv.strideB = n; gv.C = w.Hpv; gv.ldc = n; gv.strideC = n; gv.batch = Bt; gv.active = w.active;
-        VSLAM_TRY(gemm_f64(ctx, gv));
+        if (nlisted > 0) {                             // Hpv = Hcur * p
+            hipLaunchKernelGGL(bk_matvec_kernel, dim3((n + 63) / 64, nlisted), dim3(256), 0, s, w.Hcur, n, w.p, w.Hpv, listv, 1);
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+        }
         hipLaunchKernelGGL(bk_axpby_kernel, dim3(nb, Bt), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n, w.active);
         VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hpv, w.p, w.p));
         {

@@ -308,13 +308,14 @@ __device__ __forceinline__ double chain_reduce8(const double (&v)[8], int lane)
 // (the blocks it needs are final by then) and carry, unreduced, in registers into the link that uses it.
 template <bool trans, bool BANK>
 __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n, int ldS, const double *rhs, double scale, double *z, double *sol, int *err,
-                                                          size_t strideS, const int *active)
+                                                          size_t strideS, const int *active, int listed)
 {
     extern __shared__ double tc_lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, w = wave & 7;
     if (BANK) {
-        if (active && !active[blockIdx.y]) return;
-        S += (size_t)blockIdx.y * strideS; rhs += (size_t)blockIdx.y * n; z += (size_t)blockIdx.y * n;
+        const int m = instance_of(active, listed, blockIdx.y);
+        if (m < 0) return;
+        S += (size_t)m * strideS; rhs += (size_t)m * n; z += (size_t)m * n;
     }
     ChainGeo g{S, n, ldS, trans, (n + TBK - 1) / TBK};
     double *sums = sol + (size_t)g.nblk * TBK;                   // helper sums, one block of 64 per position
@@ -622,8 +623,8 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         double *sol = ctx->chain_sol + ctx->chain_used;
         ctx->chain_used += need;
         const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
-        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr);
-        else hipLaunchKernelGGL((trsv_chain_kernel<false, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr);
+        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
+        else hipLaunchKernelGGL((trsv_chain_kernel<false, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     }
@@ -641,11 +642,12 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
 }
 
 // The same solves for a bank: matrix m at S + m * strideS, right-hand side and result at rhs / z + m * n (they may be
-// the same vectors), matrices with active[m] == 0 skipped (active may be null).  False when the size is outside what
+// the same vectors), matrices with active[m] == 0 skipped (active may be null; listed: active holds `count` matrix
+// indices instead).  False when the size is outside what
 // the one-workgroup-per-matrix kernel holds in LDS (the caller then takes its own route).
 bool trsv_upper_bank_fits(int n) { return n > TBK && (n + TBK - 1) / TBK <= TC_BANK_BLOCKS; }
 vslam_status trsv_upper_bank_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, bool trans, const double *rhs, double *z,
-                                 double scale, const int *active, int count)
+                                 double scale, const int *active, int count, bool listed)
 {
     if (!trsv_upper_bank_fits(n)) return fail(ctx, VSLAM_ERR_SHAPE, "bank triangular solve: n = %d is outside 65 ... %d", n, TC_BANK_BLOCKS * TBK);
     const int nblk = (n + TBK - 1) / TBK;
@@ -655,11 +657,13 @@ vslam_status trsv_upper_bank_dev(vslam_ctx *ctx, const double *S, int n, int ldS
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int m0 = 0; m0 < count; m0 += 65535) {
         const int cnt = count - m0 < 65535 ? count - m0 : 65535;
-        const double *Sm = S + (size_t)m0 * strideS, *rm = rhs + (size_t)m0 * n;
-        double *zm = z + (size_t)m0 * n;
+        // a list carries the matrix indices itself; a mask (or no selection) counts from the first matrix of the launch
+        const size_t first = listed ? 0 : (size_t)m0;
+        const double *Sm = S + first * strideS, *rm = rhs + first * n;
+        double *zm = z + first * n;
         const int *am = active ? active + m0 : nullptr;
-        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am);
-        else hipLaunchKernelGGL((trsv_chain_kernel<false, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am);
+        if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am, listed ? 1 : 0);
+        else hipLaunchKernelGGL((trsv_chain_kernel<false, true>), dim3(1, cnt), dim3(TC_T), lds, s, Sm, n, ldS, rm, scale, zm, (double *)nullptr, ctx->flags, strideS, am, listed ? 1 : 0);
     }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
