@@ -415,3 +415,36 @@ def test_cholesky_bank_and_indefinite_matrix(ctx):
         U0 = np.linalg.cholesky(H[b]).T
         assert rel_err(U[b], U0) <= 1e-12
         assert rel_err(t[b], np.linalg.solve(U0.T, r[b])) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [40, 64, 65, 200, 462, 1000])
+def test_cholesky_of_a_shifted_matrix_without_a_copy(ctx, n):
+    """The factorisation reads H + shift I where H lies (first block row copied, the first trailing update takes the rest
+    from H); entries below the diagonal of U are not meaningful; with a list of matrices only those are touched."""
+    from visualslam_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(n)
+    B = 5
+    M = rng.standard_normal((B, n, n))
+    H = M @ np.transpose(M, (0, 2, 1)) / n + 0.1 * np.eye(n)
+    shift = np.array([0.0, 0.5, 2.0, 0.0, 7.0])
+    U = np.full((B, n, n), -7.0)
+    info = np.full(B, -1, dtype=np.int32)
+    sel = np.array([4, 0, 2], dtype=np.int32)
+    fn = L.vslam_debug_potrf_from
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    Hc = np.ascontiguousarray(H)
+    assert fn(ctx.ptr, Hc.ctypes.data, n, B, shift.ctypes.data, info.ctypes.data, U.ctypes.data, sel.ctypes.data, len(sel)) == 0, L.vslam_last_error(ctx.ptr)
+    for b in range(B):
+        Ub = U[b].T                                         # column-major on the device
+        if b not in sel:
+            assert (Ub == -7.0).all()
+            continue
+        assert info[b] == 0
+        U0 = np.linalg.cholesky(H[b] + shift[b] * np.eye(n)).T
+        assert rel_err(np.triu(Ub), U0) <= 1e-12
+    U2 = np.full((B, n, n), -7.0)
+    assert fn(ctx.ptr, Hc.ctypes.data, n, B, shift.ctypes.data, info.ctypes.data, U2.ctypes.data, None, 0) == 0
+    for b in range(B):
+        assert rel_err(np.triu(U2[b].T), np.linalg.cholesky(H[b] + shift[b] * np.eye(n)).T) <= 1e-12

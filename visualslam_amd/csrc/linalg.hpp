@@ -126,8 +126,11 @@ size_t newton_ws_bytes(int n);
 vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *info);
 // rhs (optional, one n-vector per matrix, stride_rhs apart): on return U^-T rhs -- the forward substitution rides
 // along with the factorisation as one more column of the row-panel solves and trailing updates.
+struct PotrfFrom { const double *H; size_t stride; const double *lamv; double lam; };      // factor H + shift I (lamv: device, one shift per matrix; else lam)
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower = true, double *rhs = nullptr, size_t stride_rhs = 0, bool listed = false);
+                                   bool zero_lower = true, double *rhs = nullptr, size_t stride_rhs = 0, bool listed = false,
+                                   const PotrfFrom *from = nullptr);
+// from: the matrices to factor are from->H + shift I (same ld); A receives the factors (upper triangles only) without a copy first.
 // listed: `active` holds `batch` matrix indices (the launches cover those matrices only) instead of a mask over `batch` matrices.
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,

@@ -133,6 +133,9 @@ struct CholUpdArgs {
     double *dinv; size_t stride_dinv; int *info; int j0;
     double *R; size_t strideR;     // optional right-hand side riding along as column N of the trailing block:
     int k0g, r0g;                  //   its entries beside P start at R[k0g], those beside C at R[r0g]
+    const double *Csrc;            // optional: the old values of the trailing block come from here (same layout, strideSrc apart)
+    size_t strideSrc;              //   plus a shift of the diagonal -- the first update of a factorisation that does not
+    const double *lamv; double lam; //   start from a copy of the matrix (lamv: one shift per matrix, else lam)
 };
 constexpr int UKC = 16, ULD = UKC + 2;
 // linear id -> tile (tm <= tn) of the upper triangle, column by column
@@ -162,6 +165,11 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
     const int NC = g.N + (R ? 1 : 0);                              // columns: the trailing block and the right-hand side
     auto pcol = [&](int c) -> const double * { return c == g.N ? R + g.k0g : P + (size_t)c * g.lda; };
     auto ccol = [&](int c) -> double * { return c == g.N ? R + g.r0g : C + (size_t)c * g.lda; };
+    const double *Cold = g.Csrc ? g.Csrc + (size_t)b * g.strideSrc : C;
+    auto ocol = [&](int c) -> const double * { return c == g.N ? R + g.r0g : Cold + (size_t)c * g.lda; };
+    // the shift of a source's diagonal is added where the old values are used, not where they are requested: the
+    // requests stay in flight under the products
+    const double shift = (g.Csrc && m0 == n0) ? (g.lamv ? g.lamv[b] : g.lam) : 0.0;
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
     const bool diag = m0 == n0 && (!R || n0 + CB <= g.N);      // one operand block serves both sides (not when the right-hand side is among the tile's columns)
     // old values of the tile, in the accumulator layout: [i][j][r] <-> row m0+wm+16i+l15, column n0+wn+16j+kr+4r
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = min(m0 + wm + 16 * i + l15, g.N - 1), n = min(n0 + wn + 16 * j + kr + 4 * r, NC - 1);
-                cold[i][j][r] = ccol(n)[m];
+                cold[i][j][r] = ocol(n)[m];
             }
     double4_t acc[2][2];
 #pragma unroll
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = wm + 16 * i + l15, n = wn + 16 * j + kr + 4 * r;
-                    U[m * PLD + n] = (m <= n && n < jb) ? cold[i][j][r] - acc[i][j][r] : (m == n ? 1.0 : 0.0);
+                    U[m * PLD + n] = (m <= n && n < jb) ? cold[i][j][r] + (m == n ? shift : 0.0) - acc[i][j][r] : (m == n ? 1.0 : 0.0);
                     if (R && n == g.N && m < g.N) R[g.r0g + m] = cold[i][j][r] - acc[i][j][r];    // a trailing block narrower than the tile
                 }
         __syncthreads();
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + 16 * i + l15, n = n0 + wn + 16 * j + kr + 4 * r;
-                if (m < g.N && n < NC) ccol(n)[m] = cold[i][j][r] - acc[i][j][r];
+                if (m < g.N && n < NC) ccol(n)[m] = cold[i][j][r] + (m == n ? shift : 0.0) - acc[i][j][r];
             }
 }
 
@@ -268,6 +276,20 @@ __global__ void add_diag_kernel(double *A, int lda, int n, double lam)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) A[(size_t)i * lda + i] += lam;
+}
+
+// Rows 0 ... jb-1 of the upper triangle of A := those of Src, the diagonal shifted by lam: what the first diagonal block
+// and the first row panel of a factorisation read when the matrix is not copied as a whole (the first trailing update
+// takes the rest from Src itself).  A wave per column: its lanes are the (at most 64) rows.
+__global__ void potrf_first_rows_kernel(double *A, int lda, size_t strideA, const double *Src, size_t strideSrc, int n, int jb,
+                                        const double *lamv, double lam, const int *active, int listed)
+{
+    const int b = instance_of(active, listed, blockIdx.y);
+    if (b < 0) return;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), r = threadIdx.x & 63;
+    if (c >= n || r >= jb || r > c) return;
+    const double shift = lamv ? lamv[b] : lam;
+    A[(size_t)b * strideA + (size_t)c * lda + r] = Src[(size_t)b * strideSrc + (size_t)c * lda + r] + (r == c ? shift : 0.0);
 }
 
 // strict lower triangle := 0 for matrix blockIdx.y of a batch (grid-stride over the n*n elements)
@@ -289,10 +311,15 @@ __global__ void zero_below_diag_kernel(double *A, int lda, int n, size_t strideA
 // their strict lower triangle).  zero_lower = false leaves the strict lower triangle as it is (a caller
 // that only ever reads the upper triangle of the factor saves the pass).  listed: `active` is a list of `batch`
 // matrix indices instead of a mask over `batch` matrices (info, rhs and A are still indexed by matrix).
+// from: factor from->H + shift * I (same ld, matrices from->stride apart) into A without copying it first; only the upper
+// triangle of A is then written.
 vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch, int *info, const int *active,
-                                   bool zero_lower, double *rhs, size_t stride_rhs, bool listed)
+                                   bool zero_lower, double *rhs, size_t stride_rhs, bool listed, const PotrfFrom *from)
 {
     hipStream_t s = ctx->stream;
+    if (from)
+        hipLaunchKernelGGL(potrf_first_rows_kernel, dim3((n + 3) / 4, batch), dim3(256), 0, s, A, lda, strideA, from->H, from->stride, n, n < CB ? n : CB,
+                           from->lamv, from->lam, active, listed ? 1 : 0);
     VSLAM_TRY(potf_dinv_reserve(ctx, batch));
     double *dinv = ctx->potf_dinv;
     const int extra = rhs ? 1 : 0;                    // the right-hand side rides along as column n
@@ -310,6 +337,8 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
         g.P = A + (size_t)(j0 + jb) * lda + j0; g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.N = rest; g.K = jb; g.lda = lda;
         g.strideA = strideA; g.active = active; g.listed = listed ? 1 : 0; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
         g.R = rhs; g.strideR = stride_rhs; g.k0g = j0; g.r0g = j0 + jb;
+        g.Csrc = nullptr; g.strideSrc = 0; g.lamv = nullptr; g.lam = 0.0;
+        if (from && j0 == 0) { g.Csrc = from->H + (size_t)jb * lda + jb; g.strideSrc = from->stride; g.lamv = from->lamv; g.lam = from->lam; }
         const int T = (rest + CB - 1) / CB, TC = (rest + extra + CB - 1) / CB;
         hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2 + (TC > T ? T : 0), batch), dim3(256), 0, s, g);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
@@ -466,11 +495,11 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     };
     // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&](double lam) -> vslam_status {
-        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.U, w.Hcur, nn * 8, hipMemcpyDeviceToDevice, s));
-        if (lam != 0.0) hipLaunchKernelGGL(add_diag_kernel, dim3(nb), dim3(256), 0, s, w.U, n, n, lam);
         VSLAM_HIP_TRY(ctx, hipMemcpyAsync(w.t, w.gcur, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-        // t = U^-T g comes with the factor; the strict lower triangle keeps stale values, which the solves never read
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, /*zero_lower=*/false, w.t, 0));
+        // t = U^-T g comes with the factor; Hcur is read where it lies (no copy), the strict lower triangle of U keeps
+        // stale values, which the solves never read
+        PotrfFrom from{w.Hcur, 0, nullptr, lam};
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, /*zero_lower=*/false, w.t, 0, false, &from));
         ++factorisations;
         return trsv_upper_dev(ctx, w.U, n, n, false, w.t, w.p, -1.0);
     };
@@ -583,5 +612,31 @@ extern "C" vslam_status vslam_debug_potrf(vslam_ctx *ctx, double *A, int n, int 
     VSLAM_TRY(d2h(ctx, A, dA, bytes));
     VSLAM_TRY(d2h(ctx, info, dinfo, (size_t)batch * sizeof(int)));
     if (rhs) VSLAM_TRY(d2h(ctx, rhs, dr, rbytes));
+    return stream_finish(ctx);
+}
+
+// Test hook (not part of the public header): upper Cholesky factors of H[b] + shift[b] I for `batch` symmetric n x n
+// matrices on the host, factored out of place (U, [batch][n][n] column-major, receives the upper triangles; its strict
+// lower triangles are left as the caller filled them).  sel (optional): a list of `nsel` matrix indices to factor.
+extern "C" vslam_status vslam_debug_potrf_from(vslam_ctx *ctx, const double *H, int n, int batch, const double *shift, int *info, double *U,
+                                               const int *sel, int nsel)
+{
+    using namespace vslam;
+    if (!ctx || !H || !info || !U || !shift || n < 1 || batch < 1) return VSLAM_ERR_ARG;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n, bytes = nn * batch * 8;
+    VSLAM_TRY(ws_reserve(ctx, 2 * Arena::pad(bytes) + 3 * Arena::pad((size_t)batch * 8)));
+    Arena ar(ctx->ws);
+    double *dH = ar.take<double>(nn * batch), *dU = ar.take<double>(nn * batch), *dl = ar.take<double>(batch);
+    int *dinfo = ar.take<int>(batch), *dsel = ar.take<int>(batch);
+    VSLAM_TRY(h2d(ctx, dH, H, bytes));
+    VSLAM_TRY(h2d(ctx, dU, U, bytes));
+    VSLAM_TRY(h2d(ctx, dl, shift, (size_t)batch * 8));
+    if (sel) VSLAM_TRY(h2d(ctx, dsel, sel, (size_t)nsel * sizeof(int)));
+    VSLAM_HIP_TRY(ctx, hipMemsetAsync(dinfo, 0, (size_t)batch * sizeof(int), ctx->stream));
+    PotrfFrom from{dH, nn, dl, 0.0};
+    VSLAM_TRY(potrf_upper_batch_dev(ctx, dU, n, n, nn, sel ? nsel : batch, dinfo, sel ? dsel : nullptr, false, nullptr, 0, sel != nullptr, &from));
+    VSLAM_TRY(d2h(ctx, U, dU, bytes));
+    VSLAM_TRY(d2h(ctx, info, dinfo, (size_t)batch * sizeof(int)));
     return stream_finish(ctx);
 }

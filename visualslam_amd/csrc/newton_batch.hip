@@ -194,20 +194,6 @@ __global__ void bk_gather_kernel(double *dst, const double *src, size_t count, c
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[to + i] = src[base + i];
 }
 
-// upper triangle of U[b] = that of H[b] + lam[b] I  (n x n, ld n), active instances only; the factorisation and the
-// solves that follow never touch the strict lower triangle.  One column per blockIdx.x step.
-__global__ void bk_shifted_copy_kernel(double *U, const double *H, int n, const double *lam, const int *active, int listed)
-{
-    const int b = instance_of(active, listed, blockIdx.y);
-    if (b < 0) return;
-    const size_t base = (size_t)b * n * n;
-    const double l = lam[b];
-    for (int c = blockIdx.x; c < n; c += gridDim.x) {
-        const size_t col = base + (size_t)c * n;
-        for (int r = threadIdx.x; r <= c; r += blockDim.x) U[col + r] = H[col + r] + (r == c ? l : 0.0);
-    }
-}
-
 // out[b] = a[b] - c[b] / out[b] = -(a[b] + c[b]) over `count` doubles per instance, active instances only
 __global__ void bk_sub_kernel(const double *a, const double *c, double *out, size_t count, const int *active)
 {
@@ -379,10 +365,10 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         const bool by_list = chain_trsv && nlisted < Bt;            // launches over the list of slots (the older solve kernel takes masks only)
         const int *selp = by_list ? listv : w.active;
         const int rows = by_list ? nlisted : Bt, lf = by_list ? 1 : 0;
-        hipLaunchKernelGGL(bk_shifted_copy_kernel, dim3(std::min(n, 64), rows), dim3(256), 0, s, w.U, w.Hcur, n, w.lam, selp, lf);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, rows), dim3(256), 0, s, w.t, w.gcur, (size_t)n, selp, lf);
-        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, rows, w.info, selp, /*zero_lower=*/false, w.t, (size_t)n, by_list));   // t = U^-T g comes with the factor
+        // t = U^-T g comes with the factor; Hcur + lam I is read where it lies (no shifted copy into U first)
+        PotrfFrom from{w.Hcur, nn, w.lam, 0.0};
+        VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, rows, w.info, selp, /*zero_lower=*/false, w.t, (size_t)n, by_list, &from));
         if (by_list) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, false, w.t, w.p, -1.0, selp, rows, true));
         else trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
