@@ -279,6 +279,302 @@ __device__ __attribute__((noinline)) void potf2_v3(double *U, double *invd)
     }
 }
 
+// V4: the library's routine (potf2_lds4 of visualslam_amd/csrc/potf.hpp, without the pivot check): wave 0 factors eight rows
+// at a time and applies only the last eight finished rows to them; the other waves apply those to the rows further down
+__device__ __forceinline__ void potf2_v4(double *U, double *invd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            double acc[PR];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
+            if (kb > 0) {
+#pragma unroll
+                for (int l = kb - PR; l < kb; ++l) {
+                    const double own = U[l * PLD + lane];
+                    const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb);
+                    const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+                    acc[0] -= b0.x * own; acc[1] -= b0.y * own; acc[2] -= b1.x * own; acc[3] -= b1.y * own;
+                    acc[4] -= b2.x * own; acc[5] -= b2.y * own; acc[6] -= b3.x * own; acc[7] -= b3.y * own;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(acc[r], row);
+                const double inv = rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : acc[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
+            }
+        } else if (kb > 0 && kb + PR < CB) {
+            // rows kb + 8 and beyond receive the rows kb - 8 ... kb - 1 (finished one barrier ago)
+            double own[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) own[q] = U[(kb - PR + q) * PLD + lane];
+            for (int r = kb + PR + (wave - 1); r < CB; r += 3) {
+                const double2 *bc = reinterpret_cast<const double2 *>(U + (kb - PR) * PLD + (r & ~1));
+                double a = U[r * PLD + lane];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const double2 b = bc[q * (PLD / 2)];
+                    a -= ((r & 1) ? b.y : b.x) * own[q];
+                }
+                U[r * PLD + lane] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ long long g_phase5[4];
+#define STAMP5(i) do { if (tid == 0) { const long long now_ = __builtin_readcyclecounter(); g_phase5[i] += now_ - tprev; tprev = now_; } } while (0)
+// V5: V4 with the short reciprocal square root and phase counters: wave 0 factors eight rows
+// at a time and applies only the last eight finished rows to them; the other waves apply those to the rows further down
+__device__ __forceinline__ void potf2_v5(double *U, double *invd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    long long tprev = __builtin_readcyclecounter();
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            double acc[PR];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
+            if (kb > 0) {
+#pragma unroll
+                for (int l = kb - PR; l < kb; ++l) {
+                    const double own = U[l * PLD + lane];
+                    const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb);
+                    const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+                    acc[0] -= b0.x * own; acc[1] -= b0.y * own; acc[2] -= b1.x * own; acc[3] -= b1.y * own;
+                    acc[4] -= b2.x * own; acc[5] -= b2.y * own; acc[6] -= b3.x * own; acc[7] -= b3.y * own;
+                }
+            }
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[7]));
+            STAMP5(0);
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(acc[r], row);
+                const double inv = fast_rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : acc[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
+            }
+            STAMP5(1);
+        } else if (kb > 0 && kb + PR < CB) {
+            // rows kb + 8 and beyond receive the rows kb - 8 ... kb - 1 (finished one barrier ago)
+            double own[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) own[q] = U[(kb - PR + q) * PLD + lane];
+            for (int r = kb + PR + (wave - 1); r < CB; r += 3) {
+                const double2 *bc = reinterpret_cast<const double2 *>(U + (kb - PR) * PLD + (r & ~1));
+                double a = U[r * PLD + lane];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const double2 b = bc[q * (PLD / 2)];
+                    a -= ((r & 1) ? b.y : b.x) * own[q];
+                }
+                U[r * PLD + lane] = a;
+            }
+        }
+        __syncthreads();
+        STAMP5(2);
+    }
+}
+
+// V6: as V4, but wave 0 keeps two groups of eight rows in registers: the one it factors and the next one, which
+// receives every new pivot row at once (beside the pivot chain) and, row by row in the same steps, the eight rows finished
+// one group earlier (from LDS); the other waves apply a finished group to the rows two groups further down and beyond.
+__device__ __forceinline__ void potf2_v6(double *U, double *invd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double cur[PR], nxt[PR];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < PR; ++r) { cur[r] = U[r * PLD + lane]; nxt[r] = U[(PR + r) * PLD + lane]; }
+    }
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            const bool has_next = kb + PR < CB, has_prev = kb > 0;
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(cur[r], row);
+                const double inv = fast_rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : cur[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) cur[r2] -= readlane_f64(u, kb + r2) * u;
+                if (has_next) {
+#pragma unroll
+                    for (int q = 0; q < PR; ++q) nxt[q] -= readlane_f64(u, kb + PR + q) * u;
+                    if (has_prev) {                                  // row r of the group finished before this one
+                        const int l = kb - PR + r;
+                        const double own = U[l * PLD + lane];
+                        const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb + PR);
+                        const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+                        nxt[0] -= b0.x * own; nxt[1] -= b0.y * own; nxt[2] -= b1.x * own; nxt[3] -= b1.y * own;
+                        nxt[4] -= b2.x * own; nxt[5] -= b2.y * own; nxt[6] -= b3.x * own; nxt[7] -= b3.y * own;
+                    }
+                }
+            }
+        } else if (kb > 0 && kb + 2 * PR < CB) {
+            // rows kb + 16 and beyond receive the rows kb - 8 ... kb - 1 (finished one barrier ago)
+            double own[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) own[q] = U[(kb - PR + q) * PLD + lane];
+            for (int r = kb + 2 * PR + (wave - 1); r < CB; r += 3) {
+                const double2 *bc = reinterpret_cast<const double2 *>(U + (kb - PR) * PLD + (r & ~1));
+                double a = U[r * PLD + lane];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const double2 b = bc[q * (PLD / 2)];
+                    a -= ((r & 1) ? b.y : b.x) * own[q];
+                }
+                U[r * PLD + lane] = a;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < PR; ++r) cur[r] = nxt[r];
+            if (kb + 2 * PR < CB) {
+#pragma unroll
+                for (int r = 0; r < PR; ++r) nxt[r] = U[(kb + 2 * PR + r) * PLD + lane];
+            }
+        }
+    }
+}
+
+// V7: as V6 with the new pivot rows reaching the next group one step late, as broadcast reads of the stored row;
+// V6: as V4, but wave 0 keeps two groups of eight rows in registers: the one it factors and the next one, which
+// receives every new pivot row at once (beside the pivot chain) and, row by row in the same steps, the eight rows finished
+// one group earlier (from LDS); the other waves apply a finished group to the rows two groups further down and beyond.
+__device__ __forceinline__ void potf2_v7(double *U, double *invd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double cur[PR], nxt[PR];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < PR; ++r) { cur[r] = U[r * PLD + lane]; nxt[r] = U[(PR + r) * PLD + lane]; }
+    }
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            const bool has_next = kb + PR < CB, has_prev = kb > 0;
+            double uprev = 0.0;
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(cur[r], row);
+                const double inv = fast_rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : cur[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) cur[r2] -= readlane_f64(u, kb + r2) * u;
+                if (has_next) {
+                    if (r > 0) {                                     // the pivot row of the step before: stored by now
+                        const double2 *pc = reinterpret_cast<const double2 *>(U + (row - 1) * PLD + kb + PR);
+                        const double2 p0 = pc[0], p1 = pc[1], p2 = pc[2], p3 = pc[3];
+                        nxt[0] -= p0.x * uprev; nxt[1] -= p0.y * uprev; nxt[2] -= p1.x * uprev; nxt[3] -= p1.y * uprev;
+                        nxt[4] -= p2.x * uprev; nxt[5] -= p2.y * uprev; nxt[6] -= p3.x * uprev; nxt[7] -= p3.y * uprev;
+                    }
+                    uprev = u;
+                    if (has_prev) {                                  // row r of the group finished before this one
+                        const int l = kb - PR + r;
+                        const double own = U[l * PLD + lane];
+                        const double2 *bc = reinterpret_cast<const double2 *>(U + l * PLD + kb + PR);
+                        const double2 b0 = bc[0], b1 = bc[1], b2 = bc[2], b3 = bc[3];
+                        nxt[0] -= b0.x * own; nxt[1] -= b0.y * own; nxt[2] -= b1.x * own; nxt[3] -= b1.y * own;
+                        nxt[4] -= b2.x * own; nxt[5] -= b2.y * own; nxt[6] -= b3.x * own; nxt[7] -= b3.y * own;
+                    }
+                }
+            }
+            if (has_next) {                                          // the group's last pivot row
+                const double2 *pc = reinterpret_cast<const double2 *>(U + (kb + PR - 1) * PLD + kb + PR);
+                const double2 p0 = pc[0], p1 = pc[1], p2 = pc[2], p3 = pc[3];
+                nxt[0] -= p0.x * uprev; nxt[1] -= p0.y * uprev; nxt[2] -= p1.x * uprev; nxt[3] -= p1.y * uprev;
+                nxt[4] -= p2.x * uprev; nxt[5] -= p2.y * uprev; nxt[6] -= p3.x * uprev; nxt[7] -= p3.y * uprev;
+            }
+        } else if (kb > 0 && kb + 2 * PR < CB) {
+            // rows kb + 16 and beyond receive the rows kb - 8 ... kb - 1 (finished one barrier ago)
+            double own[PR];
+#pragma unroll
+            for (int q = 0; q < PR; ++q) own[q] = U[(kb - PR + q) * PLD + lane];
+            for (int r = kb + 2 * PR + (wave - 1); r < CB; r += 3) {
+                const double2 *bc = reinterpret_cast<const double2 *>(U + (kb - PR) * PLD + (r & ~1));
+                double a = U[r * PLD + lane];
+#pragma unroll
+                for (int q = 0; q < PR; ++q) {
+                    const double2 b = bc[q * (PLD / 2)];
+                    a -= ((r & 1) ? b.y : b.x) * own[q];
+                }
+                U[r * PLD + lane] = a;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < PR; ++r) cur[r] = nxt[r];
+            if (kb + 2 * PR < CB) {
+#pragma unroll
+                for (int r = 0; r < PR; ++r) nxt[r] = U[(kb + 2 * PR + r) * PLD + lane];
+            }
+        }
+    }
+}
+
+// V8: wave 0 only factors (eight pivots per group, rows complete in LDS when it loads them); after each group all four
+// waves apply it to the next eight rows (two rows a wave, second barrier), then waves 1-3 apply it to the rows beyond
+// while wave 0 is already at the next group's pivots.
+__device__ __forceinline__ void potf2_v8(double *U, double *invd)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto apply = [&](int kb, int r) {               // row r -= the contribution of the finished rows kb ... kb + 7
+        const double2 *bc = reinterpret_cast<const double2 *>(U + kb * PLD + (r & ~1));
+        double a = U[r * PLD + lane];
+#pragma unroll
+        for (int q = 0; q < PR; ++q) {
+            const double2 b = bc[q * (PLD / 2)];
+            a -= ((r & 1) ? b.y : b.x) * U[(kb + q) * PLD + lane];
+        }
+        U[r * PLD + lane] = a;
+    };
+    for (int kb = 0; kb < CB; kb += PR) {
+        if (wave == 0) {
+            double acc[PR];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) acc[r] = U[(kb + r) * PLD + lane];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int row = kb + r;
+                const double dkk = readlane_f64(acc[r], row);
+                const double inv = fast_rsqrt(dkk);
+                const double u = (lane == row) ? dkk * inv : acc[r] * inv;
+                U[row * PLD + lane] = u;
+                if (lane == row) invd[row] = inv;
+#pragma unroll
+                for (int r2 = r + 1; r2 < PR; ++r2) acc[r2] -= readlane_f64(u, kb + r2) * u;
+            }
+        }
+        __syncthreads();
+        if (kb + PR < CB) {
+            apply(kb, kb + PR + 2 * wave);
+            apply(kb, kb + PR + 2 * wave + 1);
+            __syncthreads();
+            if (wave > 0)
+                for (int r = kb + 2 * PR + (wave - 1); r < CB; r += 3) apply(kb, r);
+        }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void probe(const double *A, double *out, long long *cycles, int reps)
 {
@@ -294,6 +590,11 @@ __global__ __launch_bounds__(256) void probe(const double *A, double *out, long 
         if (V == 1) potf2_v1(U, U + CB * PLD);
         if (V == 2) potf2_v2(U, U + CB * PLD, Yt);
         if (V == 3) potf2_v3(U, U + CB * PLD);
+        if (V == 4) potf2_v4(U, U + CB * PLD);
+        if (V == 5) potf2_v5(U, U + CB * PLD);
+        if (V == 6) potf2_v6(U, U + CB * PLD);
+        if (V == 7) potf2_v7(U, U + CB * PLD);
+        if (V == 8) potf2_v8(U, U + CB * PLD);
         __syncthreads();
         total += __builtin_readcyclecounter() - t0;
     }
@@ -342,6 +643,16 @@ int main()
     run("V1 four waves, 16-row strips: MFMA + registers + lanes", probe<1>);
     run("V2 as V1 with the sub-block inverse and MFMA strips", probe<2>);
     run("V3 as V1, pivot rows by DPP row_share", probe<3>);
+    run("V4 wave 0 factors, the other waves update the rows below", probe<4>);
+    run("V5 as V4, short reciprocal square root, phase counters", probe<5>);
+    run("V6 wave 0 holds two groups, updates beside the pivot chain", probe<6>);
+    run("V7 as V6, new pivot rows reach the next group through LDS", probe<7>);
+    run("V8 wave 0 only factors; all waves update the next eight rows", probe<8>);
+    {
+        long long ph[4];
+        CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase5), sizeof ph));
+        printf("V5 phases over 250 calls (wave 0): applying the last eight rows %lld, eight pivots %lld, barrier %lld cycles per call\n", ph[0] / 250, ph[1] / 250, ph[2] / 250);
+    }
     {
         long long ph[4];
         CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph));
