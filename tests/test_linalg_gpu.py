@@ -163,6 +163,37 @@ def test_two_contexts_factor_large_matrices_at_once(ctx):
         c_.close()
 
 
+def test_two_contexts_solve_large_triangular_systems_at_once(ctx):
+    """Two host threads, each with a context of its own, queue chained triangular solves of 9000 unknowns (139 workgroups
+    that wait for one another per solve: two at once do not fit the chip).  The library queues such launches one after
+    the other on the GPU; both threads get their solutions."""
+    import threading
+    import scipy.linalg as sla
+    from visualslam_amd import _lib, api
+    L = _lib.lib()
+    fn = L.vslam_debug_trsv_reps
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n = 9000
+    rng = np.random.default_rng(90)
+    jobs = []
+    for t in range(2):
+        U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + np.diag(1.0 + rng.random(n))
+        jobs.append({"U": U, "S": np.ascontiguousarray(U.T), "b": rng.standard_normal(n), "z": np.zeros(n), "ctx": api.Context(0), "rc": None, "trans": t})
+    def run(j):
+        j["rc"] = fn(j["ctx"].ptr, j["S"].ctypes.data, n, j["trans"], j["b"].ctypes.data, j["z"].ctypes.data, 40)
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for j in jobs:
+        assert j["rc"] == 0, L.vslam_last_error(j["ctx"].ptr)
+        z0 = sla.solve_triangular(j["U"], j["b"], trans=j["trans"], lower=False)
+        assert rel_err(j["z"], z0) <= 1e-11
+        j["ctx"].close()
+
+
 def test_qr_tall_batched_many_workgroups(ctx):
     import torch
     from visualslam_amd import api

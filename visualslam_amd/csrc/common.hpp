@@ -122,6 +122,24 @@ struct CamK {
 };
 vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *out);
 
+// Launches whose workgroups wait for one another (the blocked QR's exchange, the chained triangular solve with helper
+// workgroups) are queued one after the other on each GPU, whatever context or stream they come from: while the guard
+// lives, the stream has been made to wait for the event the previous such call recorded at its end, and the guard's end
+// records this call's.  Workgroups of two of them can then never hold compute units while waiting for members that found
+// none free.  Nothing blocks on the host beyond the mutex around the enqueue.
+class DeviceTurnGuard {
+public:
+    explicit DeviceTurnGuard(vslam_ctx *ctx);
+    ~DeviceTurnGuard();
+    vslam_status status() const { return st_; }
+    DeviceTurnGuard(const DeviceTurnGuard &) = delete;
+    DeviceTurnGuard &operator=(const DeviceTurnGuard &) = delete;
+private:
+    vslam_ctx *ctx_;
+    vslam_status st_;
+    bool held_;
+};
+
 // Which instance of a bank row y of a grid works on: every row its own (sel null), the rows whose mask word is
 // non-zero (listed == 0: the grid covers all instances, the others leave at once) or the y-th entry of a list of
 // instances (listed != 0: the grid covers the list only -- a launch over a thousand instances of which a handful

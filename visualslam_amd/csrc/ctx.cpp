@@ -1,5 +1,6 @@
 // Context lifecycle, status strings, camera.xml reader.
 #include "common.hpp"
+#include <mutex>
 
 #include <cmath>
 #include <cstdlib>
@@ -155,6 +156,31 @@ vslam_status side_stream_init(vslam_ctx *ctx)
     VSLAM_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     for (int i = 0; i < 6; ++i) VSLAM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     return VSLAM_OK;
+}
+
+namespace {
+struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
+DeviceTurn g_turn[64];
+}
+
+DeviceTurnGuard::DeviceTurnGuard(vslam_ctx *ctx) : ctx_(ctx), st_(VSLAM_OK), held_(false)
+{
+    if (ctx->device < 0 || ctx->device >= 64) return;           // no queue for such a device: the call runs unguarded
+    DeviceTurn &turn = g_turn[ctx->device];
+    turn.m.lock();
+    held_ = true;
+    hipError_t e = hipSuccess;
+    if (turn.last) e = hipStreamWaitEvent(ctx->stream, turn.last, 0);
+    else e = hipEventCreateWithFlags(&turn.last, hipEventDisableTiming);
+    if (e != hipSuccess) st_ = fail(ctx, VSLAM_ERR_DEVICE, "device turn: %s", hipGetErrorString(e));
+}
+
+DeviceTurnGuard::~DeviceTurnGuard()
+{
+    if (!held_) return;
+    DeviceTurn &turn = g_turn[ctx_->device];
+    if (turn.last) (void)hipEventRecord(turn.last, ctx_->stream);    // also after a failed enqueue: what was queued still runs
+    turn.m.unlock();
 }
 
 vslam_status stream_finish(vslam_ctx *ctx)

@@ -942,30 +942,19 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
     return VSLAM_OK;
 }
 
-// Factorisations whose workgroups wait for one another (qr_block_kernel with more than one workgroup per matrix) are
-// queued one after the other on each GPU, whatever context or stream they come from: every such call first makes its
-// stream wait for the event the previous one recorded at its end, and records its own.  Workgroups of two of them
-// can then never hold compute units while waiting for members that found none free.  Nothing blocks on the host.
-namespace {
-struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
-DeviceTurn g_turn[64];
-}
-
+// Factorisations whose workgroups wait for one another (qr_block_kernel with more than one workgroup per matrix) take the
+// GPU's turn (DeviceTurnGuard).
 static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws);
 
 vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
 {
     QrBlockPlan pl;
     const bool waits = rows >= 1 && cols >= 1 && batch >= 1 && qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl) && pl.G > 1 &&
-                       ctx->device >= 0 && ctx->device < 64;
+                       true;
     if (!waits) return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
-    DeviceTurn &turn = g_turn[ctx->device];
-    std::lock_guard<std::mutex> lock(turn.m);
-    if (turn.last) VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, turn.last, 0));
-    else VSLAM_HIP_TRY(ctx, hipEventCreateWithFlags(&turn.last, hipEventDisableTiming));
-    const vslam_status st = qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
-    VSLAM_HIP_TRY(ctx, hipEventRecord(turn.last, ctx->stream));      // also after a failed enqueue: what was queued still runs
-    return st;
+    DeviceTurnGuard turn(ctx);                        // queued behind the previous such factorisation or solve on this GPU
+    if (turn.status() != VSLAM_OK) return turn.status();
+    return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
 }
 
 static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)

@@ -623,6 +623,16 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         double *sol = ctx->chain_sol + ctx->chain_used;
         ctx->chain_used += need;
         const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
+        // More workgroups than the blocked QR's launcher leaves free (it keeps to 240 of 256 compute units): take the GPU's
+        // turn, so that this launch and such a factorisation from another context never wait for members that found no room.
+        if (1 + helpers > 16) {
+            DeviceTurnGuard turn(ctx);
+            if (turn.status() != VSLAM_OK) return turn.status();
+            if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
+            else hipLaunchKernelGGL((trsv_chain_kernel<false, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+            return VSLAM_OK;
+        }
         if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
         else hipLaunchKernelGGL((trsv_chain_kernel<false, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
@@ -693,7 +703,13 @@ extern "C" vslam_status vslam_debug_trtri(vslam_ctx *ctx, const double *S, int n
 
 // Test hook (not part of the public header): z = S^-1 b (trans = 0) or S^-T b (trans = 1) for one upper-triangular
 // n x n matrix on the host (column-major, ld n).
+extern "C" vslam_status vslam_debug_trsv_reps(vslam_ctx *ctx, const double *S, int n, int trans, const double *b, double *z, int reps);
 extern "C" vslam_status vslam_debug_trsv(vslam_ctx *ctx, const double *S, int n, int trans, const double *b, double *z)
+{
+    return vslam_debug_trsv_reps(ctx, S, n, trans, b, z, 1);
+}
+// The same solve queued `reps` times back to back (the matrix goes to the device once).
+extern "C" vslam_status vslam_debug_trsv_reps(vslam_ctx *ctx, const double *S, int n, int trans, const double *b, double *z, int reps)
 {
     using namespace vslam;
     if (!ctx || !S || !b || !z || n < 1) return VSLAM_ERR_ARG;
@@ -704,7 +720,7 @@ extern "C" vslam_status vslam_debug_trsv(vslam_ctx *ctx, const double *S, int n,
     double *dS = ar.take<double>(nn), *db = ar.take<double>(n), *dz = ar.take<double>(n);
     VSLAM_TRY(h2d(ctx, dS, S, nn * 8));
     VSLAM_TRY(h2d(ctx, db, b, (size_t)n * 8));
-    VSLAM_TRY(trsv_upper_dev(ctx, dS, n, n, trans != 0, db, dz));
+    for (int rep = 0; rep < (reps < 1 ? 1 : reps); ++rep) VSLAM_TRY(trsv_upper_dev(ctx, dS, n, n, trans != 0, db, dz));
     VSLAM_TRY(d2h(ctx, z, dz, (size_t)n * 8));
     return stream_finish(ctx);
 }
