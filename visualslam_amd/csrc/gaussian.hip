@@ -192,7 +192,9 @@ vslam_status log_gaussian_dev(vslam_ctx *ctx, const double *x, const double *mu,
         GemmDesc d;                                                       // H = -W W^T
         d.M = n; d.N = n; d.K = n; d.transA = false; d.transB = true; d.amode = A_UPPER; d.b_upper = true; d.alpha = -1.0;
         d.A = Wbuf; d.lda = n; d.B = Wbuf; d.ldb = n; d.C = H; d.ldc = n;
+        d.c_upper = true;                                                 // the product is symmetric: upper tiles, then mirrored
         VSLAM_TRY(gemm_f64(ctx, d));
+        VSLAM_TRY(mirror_upper_dev(ctx, H, n, n, 0, 1));
     }
     return VSLAM_OK;
 }

@@ -78,6 +78,9 @@ size_t trtri_batch_ws_bytes(int n, int batch);
 vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
                                    int batch, void *ws);
 
+// Strict lower triangle := transpose of the strict upper triangle (batch matrices strideA apart).
+vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch);
+
 // Solves S^T x = b (trans = true) or S x = b (trans = false) for one vector, S upper triangular (the strict lower
 // triangle is never read); z = scale * x.  b and z may be the same vector.
 vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, bool trans, const double *b, double *z, double scale = 1.0);

@@ -651,6 +651,40 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
     return VSLAM_OK;
 }
 
+// Strict lower triangle := transpose of the strict upper triangle, for `batch` n x n matrices strideA apart: what a
+// symmetric product computed on its upper tiles only needs before something reads the whole matrix.  One workgroup per
+// 64 x 64 tile on or above the diagonal, the transposition through LDS so that reads and writes both run along columns.
+__global__ __launch_bounds__(256) void mirror_upper_kernel(double *A, int n, int lda, size_t strideA, int T)
+{
+    __shared__ double tile[64][65];
+    // linear id -> (ti <= tj), column by column
+    int l = blockIdx.x, tj = (int)((sqrtf(8.0f * (float)l + 1.0f) - 1.0f) * 0.5f);
+    while ((tj + 1) * (tj + 2) / 2 <= l) ++tj;
+    while (tj * (tj + 1) / 2 > l) --tj;
+    const int ti = l - tj * (tj + 1) / 2, i0 = ti * 64, j0 = tj * 64;
+    double *Ab = A + (size_t)blockIdx.y * strideA;
+    const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int r = i0 + a, c = j0 + 4 * p + q;
+        tile[4 * p + q][a] = (r < n && c < n) ? Ab[(size_t)c * lda + r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int row = j0 + a, col = i0 + 4 * p + q;             // element (row, col) of the lower triangle = upper (col, row)
+        if (row < n && col < n && row > col) Ab[(size_t)col * lda + row] = tile[a][4 * p + q];
+    }
+}
+
+vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch)
+{
+    const int T = (n + 63) / 64;
+    hipLaunchKernelGGL(mirror_upper_kernel, dim3(T * (T + 1) / 2, batch), dim3(256), 0, ctx->stream, A, n, lda, strideA, T);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
 // The same solves for a bank: matrix m at S + m * strideS, right-hand side and result at rhs / z + m * n (they may be
 // the same vectors), matrices with active[m] == 0 skipped (active may be null; listed: active holds `count` matrix
 // indices instead).  False when the size is outside what
