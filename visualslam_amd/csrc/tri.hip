@@ -211,11 +211,13 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
 // Helper workgroup b accumulates, for position TC_LAG-1+b, the contributions of all positions at least TC_LAG
 // back as their solutions appear and publishes the 64 sums.  Those travel through memory (two trips and a little
 // arithmetic), which the TC_LAG-1 links in between cover.
-// Published values are their own ready marks: `sol` (solutions, then sums) is filled with a NaN of all-ones bits
-// before the launch and a reader polls until the pattern is gone.  (A value that is itself this NaN -- only a
-// right-hand side holding the same pattern produces one -- ends in the bounded wait below.)  All workgroups are
-// resident together (at most TC_MAX of 256 compute units, one workgroup each); a wait that exceeds its bound
-// raises *err and lets every wave run to the end.
+// Published values are their own ready marks: `sol` (solutions, then sums: a stretch of the context's ring that no
+// earlier launch has used since the ring was last filled) holds a NaN of all-ones bits and a reader polls until the
+// pattern is gone.  (A value that is itself this NaN -- only a right-hand side holding the same pattern produces
+// one -- ends in the bounded wait below.)  All workgroups are resident together (at most TC_MAX of 256 compute
+// units, one workgroup each; a launch of more than 16 takes the GPU's turn, see trsv_upper_dev); a wait that
+// exceeds its bound raises *err and lets every wave run to the end.
+// rhs and z may be the same vector (an entry is read one link before it is written); z = scale * solution.
 constexpr int TC_MAX = 240;
 constexpr int TC_LAG = 3;
 constexpr int TC_BANK_BLOCKS = 16;                            // a bank matrix has at most this many blocks (its solution stays in LDS)
