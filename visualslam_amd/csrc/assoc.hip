@@ -122,11 +122,70 @@ __device__ __forceinline__ void wave_qr2(const double *c0, const double *c1, int
     *r00 = beta; *r01 = c1[0] - d; *r11 = b1;
 }
 
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One wave, work vectors in LDS: the two new reflectors of a landmark's columns c0 = ca[0..N), c1 = ca[N..2N) on rows
+// k.. (make_reflector, apply_reflector, make_reflector with the same conventions), the coupling of the two columns
+// with z_prev and v1^T v0 for the commit -- the whole serial part of a landmark without a workgroup barrier (a
+// workgroup-wide sum costs two barriers of sixteen waves for vectors a single wave holds in a few elements per lane).
+// out: beta0, tau0, r01, beta1, tau1, c0 . z, c1 . z, v1^T v0.  On return ca holds the scaled reflector tails as
+// the workgroup-wide routines leave them.
+__device__ void wave_panel(double *ca, const double *z, int k, int N, double *out)
+{
+    const int lane = threadIdx.x & 63;
+    double *c0 = ca, *c1 = ca + N;
+    // coupling with z_prev (rows < k are not touched below)
+    double p0 = 0.0, p1 = 0.0;
+    for (int r = lane; r < k; r += 64) { const double zr = z[r]; p0 += c0[r] * zr; p1 += c1[r] * zr; }
+    p0 = wave_sum(p0); p1 = wave_sum(p1);
+    // reflector 0 and what it needs of column 1 in one pass
+    double t0 = 0.0, d01 = 0.0;
+    for (int r = k + 1 + lane; r < N; r += 64) { const double x = c0[r]; t0 += x * x; d01 += x * c1[r]; }
+    t0 = wave_sum(t0); d01 = wave_sum(d01);
+    const double alpha0 = c0[k];
+    double beta0, tau0, scale0;
+    if (t0 <= 2.2250738585072014e-308) { beta0 = alpha0; tau0 = 0.0; scale0 = 0.0; }
+    else {
+        beta0 = sqrt(alpha0 * alpha0 + t0);
+        if (alpha0 >= 0.0) beta0 = -beta0;
+        scale0 = 1.0 / (alpha0 - beta0);
+        tau0 = (beta0 - alpha0) / beta0;
+    }
+    const double d = tau0 * (c1[k] + scale0 * d01);            // tau0 * v0^T c1
+    const double r01 = c1[k] - d;
+    // scale the tail of column 0, apply the reflector to column 1, and gather reflector 1's sums on the way
+    double t1 = 0.0;
+    for (int r = k + 1 + lane; r < N; r += 64) {
+        const double v = c0[r] * scale0, y = c1[r] - d * v;
+        c0[r] = v; c1[r] = y;
+        if (r > k + 1) t1 += y * y;
+    }
+    if (lane == 0) c1[k] = r01;
+    t1 = wave_sum(t1);
+    double beta1, tau1 = 0.0, scale1 = 0.0;
+    const double alpha1 = (k + 1 < N) ? c1[k + 1] : 0.0;
+    if (k + 1 >= N || t1 <= 2.2250738585072014e-308) beta1 = alpha1;
+    else {
+        beta1 = sqrt(alpha1 * alpha1 + t1);
+        if (alpha1 >= 0.0) beta1 = -beta1;
+        scale1 = 1.0 / (alpha1 - beta1);
+        tau1 = (beta1 - alpha1) / beta1;
+    }
+    double ps = 0.0;                                             // v1^T v0 = v0(k+1) + sum_{r >= k+2} v0(r) v1(r)
+    for (int r = k + 2 + lane; r < N; r += 64) { const double v = c1[r] * scale1; c1[r] = v; ps += c0[r] * v; }
+    ps = wave_sum(ps) + ((k + 1 < N) ? c0[k + 1] : 0.0);
+    if (lane == 0) { out[0] = beta0; out[1] = tau0; out[2] = r01; out[3] = beta1; out[4] = tau1; out[5] = p0; out[6] = p1; out[7] = ps; }
+}
+
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
-    __shared__ double sh[16];
-    __shared__ int shi[4];
+    __shared__ double pn[8];                 // results of wave_panel
+    __shared__ double cand_z0[AT / 64], cand_z1[AT / 64];
     __shared__ double cand_v[AT / 64];
     __shared__ int cand_i[AT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, inst = blockIdx.x;
@@ -160,15 +219,22 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         for (int r = tid; r < 2 * N; r += AT) ca[r] = W[(size_t)(2 * j) * N + r];
         __syncthreads();
         // ---- two new reflectors on rows k.. (joint factor) ----
-        double tau0, tau1;
-        const double beta0 = make_reflector(ca, k, N, red, &tau0);
-        apply_reflector(ca, tau0, k, N, ca + N, red);
-        const double r01 = ca[N + k];
-        const double beta1 = (k + 1 < N) ? make_reflector(ca + N, k + 1, N, red, &tau1) : (tau1 = 0.0, ca[N + k + 1]);
-        // coupling of the new columns with z_prev: c_q = r12(:, q)^T z_prev
-        double p0 = 0.0, p1 = 0.0;
-        for (int r = tid; r < k; r += AT) { p0 += ca[r] * z[r]; p1 += ca[N + r] * z[r]; }
-        const double c0 = wg_sum(p0, red), c1 = wg_sum(p1, red);
+        double tau0, tau1, beta0, beta1, r01, c0, c1, s01 = 0.0;
+        if (a.vec_lds) {
+            // the vectors live in LDS: one wave does the serial part, everybody else meets it at one barrier
+            if (wave == 0) wave_panel(ca, z, k, N, pn);
+            __syncthreads();
+            beta0 = pn[0]; tau0 = pn[1]; r01 = pn[2]; beta1 = pn[3]; tau1 = pn[4]; c0 = pn[5]; c1 = pn[6]; s01 = pn[7];
+        } else {
+            beta0 = make_reflector(ca, k, N, red, &tau0);
+            apply_reflector(ca, tau0, k, N, ca + N, red);
+            r01 = ca[N + k];
+            beta1 = (k + 1 < N) ? make_reflector(ca + N, k + 1, N, red, &tau1) : (tau1 = 0.0, ca[N + k + 1]);
+            // coupling of the new columns with z_prev: c_q = r12(:, q)^T z_prev
+            double p0 = 0.0, p1 = 0.0;
+            for (int r = tid; r < k; r += AT) { p0 += ca[r] * z[r]; p1 += ca[N + r] * z[r]; }
+            c0 = wg_sum(p0, red); c1 = wg_sum(p1, red);
+        }
         double best_ds = INFINITY, best_z0 = 0.0, best_z1 = 0.0;
         int best_i = -1;
         const double scur = s;
@@ -200,19 +266,17 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
                 const int oi = __shfl_xor(my_i, off, 64);
                 if (ods < my_ds || (ods == my_ds && oi < my_i)) { my_ds = ods; my_i = oi; my_z0 = oz0; my_z1 = oz1; }
             }
+            // every wave's best to LDS, then every thread picks the winner itself (the arrays are written again only
+            // behind the barrier that ends this landmark)
+            if (lane == 0) { cand_v[wave] = my_ds; cand_i[wave] = my_i; cand_z0[wave] = my_z0; cand_z1[wave] = my_z1; }
             __syncthreads();
-            if (lane == 0) { cand_v[wave] = my_ds; cand_i[wave] = my_i; }
-            __syncthreads();
-            if (tid == 0) {
+            {
                 int bw = 0;
+#pragma unroll
                 for (int q = 1; q < AT / 64; ++q)
                     if (cand_v[q] < cand_v[bw] || (cand_v[q] == cand_v[bw] && cand_i[q] < cand_i[bw])) bw = q;
-                shi[0] = bw;
+                if (cand_v[bw] < INFINITY) { best_ds = cand_v[bw]; best_z0 = cand_z0[bw]; best_z1 = cand_z1[bw]; best_i = cand_i[bw]; }
             }
-            __syncthreads();
-            if (wave == shi[0] && lane == 0) { sh[0] = my_ds; sh[1] = my_z0; sh[2] = my_z1; shi[1] = my_i; }
-            __syncthreads();
-            if (sh[0] < INFINITY) { best_ds = sh[0]; best_z0 = sh[1]; best_z1 = sh[2]; best_i = shi[1]; }
             // landmark j left unassociated (:133-142)
             const double sA = nA > 0 ? (2 * nA * halflog2pi + logdet) + 0.5 * zz : 0.0;
             const double su = sA + (n - nA) * a.sU;
@@ -239,9 +303,11 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         // v0 = [1 at k; ca(k+1..)], v1 = [1 at k+1; ca(N + k+2..)].  With s01 = v1^T v0 both act in one read pass
         // and one update pass per column:  a -= tau0 d0 v0 + tau1 (e1 - tau0 d0 s01) v1,  d0 = v0^T a, e1 = v1^T a. ----
         {
-            double ps = (tid == 0 && k + 1 < N) ? ca[k + 1] : 0.0;                       // v1(k+1) = 1 times v0(k+1)
-            for (int r = k + 2 + tid; r < N; r += AT) ps += ca[r] * ca[N + r];
-            const double s01 = wg_sum(ps, red);
+            if (!a.vec_lds) {
+                double ps = (tid == 0 && k + 1 < N) ? ca[k + 1] : 0.0;                   // v1(k+1) = 1 times v0(k+1)
+                for (int r = k + 2 + tid; r < N; r += AT) ps += ca[r] * ca[N + r];
+                s01 = wg_sum(ps, red);
+            }
             constexpr int CG = 4;                                                        // columns a wave handles at once
             for (int c0 = 2 * (j + 1) + wave * CG; c0 < N; c0 += (AT / 64) * CG) {
                 double d0[CG], e1[CG];
