@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void bk_reverse_kernel(const double *A, int n,
 // B filters and Bt - B further slots in which trust-region subproblems of the same filters are solved ahead
 // (iekf_bank_chunk): the slots beyond B own a factor, a current Hessian and the vectors, nothing else.
 struct BankWs {
-    double *Hp, *Hl, *H, *W;                                                // [B][n*n]
+    double *Hp, *Hl, *W;                                                    // [B][n*n]
     double *U, *Hcur;                                                       // [Bt][n*n]
     double *x, *tmp, *gp, *gl, *g, *xcur, *gcur, *p, *t, *q, *xn, *Hpv;     // [Bt][n]
     double *vp, *vl, *V, *dots, *lam;                                       // [Bt] ([Bt][4] for dots)
@@ -259,7 +259,7 @@ struct BankWs {
 size_t bank_ws_bytes(int n, int B, int Bt)
 {
     const size_t nn = (size_t)n * n;
-    return 4 * Arena::pad((size_t)B * nn * 8) + 2 * Arena::pad((size_t)Bt * nn * 8) + 12 * Arena::pad((size_t)Bt * n * 8) +
+    return 3 * Arena::pad((size_t)B * nn * 8) + 2 * Arena::pad((size_t)Bt * nn * 8) + 12 * Arena::pad((size_t)Bt * n * 8) +
            9 * Arena::pad((size_t)Bt * 4 * 8) + trtri_batch_ws_bytes(n, B);
 }
 
@@ -267,7 +267,7 @@ void bank_carve(void *ws, int n, int B, int Bt, BankWs *w)
 {
     Arena ar(ws);
     const size_t nn = (size_t)n * n;
-    w->Hp = ar.take<double>(B * nn); w->Hl = ar.take<double>(B * nn); w->H = ar.take<double>(B * nn);
+    w->Hp = ar.take<double>(B * nn); w->Hl = ar.take<double>(B * nn);
     w->W = ar.take<double>(B * nn); w->U = ar.take<double>(Bt * nn); w->Hcur = ar.take<double>(Bt * nn);
     double **v[12] = {&w->x, &w->tmp, &w->gp, &w->gl, &w->g, &w->xcur, &w->gcur, &w->p, &w->t, &w->q, &w->xn, &w->Hpv};
     for (double **q : v) *q = ar.take<double>((size_t)Bt * n);
@@ -396,7 +396,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         VSLAM_TRY(launch_point_loglik(ctx, k, B, n, w.x, n, y, 2 * (size_t)L, vis, L, sigma, w.vl, w.gl, n, w.Hl, n, nn, nullptr, a));
         hipLaunchKernelGGL(bk_neg_sum_kernel, dim3(1, B), dim3(64), 0, s, w.vp, w.vl, w.V, (size_t)1, a);
         hipLaunchKernelGGL(bk_neg_sum_kernel, dim3(1, B), dim3(256), 0, s, w.gp, w.gl, w.g, (size_t)n, a);
-        hipLaunchKernelGGL(bk_neg_sum_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.Hp, w.Hl, w.H, nn, a);
+        // the Hessian -(Hp + Hl) of a point is only ever wanted when the point is accepted: accept() forms it there
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         VSLAM_TRY(d2h(ctx, V.data(), w.V, (size_t)B * 8));
         return stream_sync(ctx);
@@ -405,7 +405,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     auto accept = [&]() {
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.xcur, w.x, (size_t)n, w.active);
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.gcur, w.g, (size_t)n, w.active);
-        hipLaunchKernelGGL(bk_copy_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.Hcur, w.H, nn, w.active);
+        hipLaunchKernelGGL(bk_neg_sum_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.Hp, w.Hl, w.Hcur, nn, w.active);      // Hcur = -(Hp + Hl) of the point just evaluated
     };
     // dst[slot] = src[map[slot]] for the slots whose map entry is not negative
     auto gather = [&](double *dst, const double *src, size_t count, int slots) {
@@ -612,7 +612,7 @@ extern "C" vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, 
     const size_t nn = (size_t)n * n;
     const int L = (n - 12) / 3;
     // instances per pass: the work matrices of one pass stay under 16 GiB
-    size_t chunk = ((size_t)16 << 30) / (9 * nn * 8);
+    size_t chunk = ((size_t)16 << 30) / (8 * nn * 8);
     chunk = std::max<size_t>(1, std::min<size_t>(chunk, 16384));
     for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
         const int B = std::min<int>((int)chunk, batch - b0);
