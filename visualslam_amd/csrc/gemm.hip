@@ -101,7 +101,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g)
     int tile_m, tile_n;
     {
         const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, q = nb >> 3, r = nb & 7;
-        const int l = x * q + min(x, r) + ((int)blockIdx.x >> 3);
+        // (A triangular operand makes the tiles' K ranges run from a whole K down to one block along the order: a contiguous
+        // run per XCD would give one XCD all the long tiles, so there the ids stay as dealt, every XCD a mix.)
+        const bool ragged_k = g.amode == A_UPPER || g.b_upper;
+        const int l = ragged_k ? (int)blockIdx.x : x * q + min(x, r) + ((int)blockIdx.x >> 3);
         if (g.c_upper) upper_tile_of(l, g.tilesM, g.tilesN, BM, BN, &tile_m, &tile_n);
         else {
             const int per_group = 8 * g.tilesN, group = l / per_group, first_m = group * 8;
