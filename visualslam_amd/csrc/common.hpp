@@ -140,6 +140,26 @@ private:
     bool held_;
 };
 
+// A grid of (items, rows) workgroups over a bank, rows being its matrices: the hardware deals workgroup ids round-robin
+// to the eight XCDs, which would spread the items of one matrix over all eight L2 caches.  This renumbering gives
+// every XCD whole matrices instead (all items of row r on XCD r mod 8), so that what the items of a matrix share -- the
+// row panel of a factorisation step -- is fetched into one L2 once.  The last rows mod 8 keep the plain numbering.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void bank_grid_xcd(int *item, int *row)
+{
+    const int T = (int)gridDim.x, R = (int)gridDim.y, full = R & ~7;
+    const int L = (int)blockIdx.y * T + (int)blockIdx.x;
+    if (L < full * T) {
+        const int xcd = L & 7, idx = L >> 3;
+        *row = xcd + 8 * (idx / T);
+        *item = idx % T;
+    } else {
+        *row = (int)blockIdx.y;
+        *item = (int)blockIdx.x;
+    }
+}
+#endif
+
 // Which instance of a bank row y of a grid works on: every row its own (sel null), the rows whose mask word is
 // non-zero (listed == 0: the grid covers all instances, the others leave at once) or the y-th entry of a list of
 // instances (listed != 0: the grid covers the list only -- a launch over a thousand instances of which a handful

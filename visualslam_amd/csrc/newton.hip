@@ -70,12 +70,14 @@ __global__ __launch_bounds__(256) void potrf_trsm_kernel(double *A, int lda, int
     __shared__ __align__(16) double U[CB * PLD];                   // U[l][j] at l * PLD + j (upper triangle meaningful)
     __shared__ double Yt[4 * 16 * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
-    const int b = instance_of(active, listed, blockIdx.y);
+    int bx, by;
+    bank_grid_xcd(&bx, &by);                                       // a matrix's column blocks on one XCD: the update finds the panel in that L2
+    const int b = instance_of(active, listed, by);
     if (b < 0) return;
     A += (size_t)b * strideA;
-    dinv += (size_t)blockIdx.y * stride_dinv;                      // scratch of the grid row, as the kernels before and after use it
+    dinv += (size_t)by * stride_dinv;                              // scratch of the grid row, as the kernels before and after use it
     const int jb = min(CB, n - j0);                                // the last block row may be short (then only R is to its right)
-    const int c0 = j0 + jb + blockIdx.x * CB;
+    const int c0 = j0 + jb + bx * CB;
     const int col = c0 + 16 * wave + l15;
     const bool cok = col < n + (R ? 1 : 0);
     // right-hand side: block bi, register q <-> row 16 bi + 4 q + kr of this lane's column
@@ -152,12 +154,14 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
     static_assert(2 * CB * ULD <= POTF_LDS_DOUBLES, "operand chunks fit");
     double *const Pm = Ps, *const Pn = Ps + CB * ULD;                 // [column of the tile][row of the chunk]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kr = lane >> 4;
-    const int b = instance_of(g.active, g.listed, blockIdx.y);
+    int bx, by;
+    bank_grid_xcd(&bx, &by);                                       // the tiles of a matrix on one XCD: its row panel is fetched into one L2
+    const int b = instance_of(g.active, g.listed, by);
     if (b < 0) return;
     const int T = (g.N + CB - 1) / CB, tri = T * (T + 1) / 2;
     int tile_m, tile_n;
-    if ((int)blockIdx.x < tri) upper_tile(blockIdx.x, &tile_m, &tile_n);
-    else { tile_n = T; tile_m = (int)blockIdx.x - tri; }           // the right-hand side in a tile column of its own
+    if (bx < tri) upper_tile(bx, &tile_m, &tile_n);
+    else { tile_n = T; tile_m = bx - tri; }           // the right-hand side in a tile column of its own
     const int m0 = tile_m * CB, n0 = tile_n * CB;
     const double *P = g.P + (size_t)b * g.strideA;
     double *C = g.C + (size_t)b * g.strideA;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const double *Bn = diag ? Pm : Pn;
-    if (blockIdx.x == 0 && g.K <= CB && diag) {
+    if (bx == 0 && g.K <= CB && diag) {
         // tile (0, 0) heads the chain of diagonal blocks: its K x 64 operand in one trip through memory
         // (lane = row, a wave fetches whole columns), then the products straight through
         double ra[16];
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bn[j], am[i], acc[i][j], 0, 0, 0);
         }
     }
-    if (blockIdx.x == 0) {                                          // tile (0, 0): the next diagonal block
+    if (bx == 0) {                                                  // tile (0, 0): the next diagonal block
         __syncthreads();
         double *U = Ps, *invd = Ps + CB * PLD;
         const int jb = min(CB, g.N);
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
                 }
         __syncthreads();
         potf2_lds4(U, invd, jb, g.j0, g.info + b);
-        potf_dinv16(U, invd, g.dinv + (size_t)blockIdx.y * g.stride_dinv);       // scratch of the grid row (the row panel kernel reads it there)
+        potf_dinv16(U, invd, g.dinv + (size_t)by * g.stride_dinv);       // scratch of the grid row (the row panel kernel reads it there)
         for (int c = wave; c < jb; c += 4)
             if (lane <= c) C[(size_t)c * g.lda + lane] = U[lane * PLD + c];
         return;
