@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -125,10 +126,11 @@ __global__ __launch_bounds__(BK_T) void bk_trsv_kernel(const double *S, int ldS,
 
 // out[b][q] = a_q[b] . b_q[b], q < 3 (null pairs give 0); one workgroup per active instance.
 struct BkDotArgs { const double *a[3]; const double *b[3]; };
-__global__ __launch_bounds__(BK_T) void bk_dots_kernel(BkDotArgs d, int n, double *out, const int *active)
+__global__ __launch_bounds__(BK_T) void bk_dots_kernel(BkDotArgs d, int n, double *out, const int *active, const int *info)
 {
     __shared__ double red[3][BK_T / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (info && tid == 0) out[(size_t)b * 4 + 3] = (double)info[b];      // every slot's factorisation flag travels with the dot products
     if (active && !active[b]) return;
     double acc[3] = {0.0, 0.0, 0.0};
     for (int i = tid; i < n; i += BK_T)
@@ -273,7 +275,9 @@ void bank_carve(void *ws, int n, int B, int Bt, BankWs *w)
     for (double **q : v) *q = ar.take<double>((size_t)Bt * n);
     w->vp = ar.take<double>(4 * Bt); w->vl = ar.take<double>(4 * Bt); w->V = ar.take<double>(4 * Bt);
     w->dots = ar.take<double>(4 * Bt); w->lam = ar.take<double>(4 * Bt);
-    w->info = reinterpret_cast<int *>(ar.take<double>(4 * Bt)); w->active = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
+    w->info = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
+    ar.take<double>(4 * Bt);
+    w->active = reinterpret_cast<int *>(w->lam + Bt);      // mask and list sit behind the multipliers: one upload carries all three
     w->map = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
     ar.take<double>(4 * Bt);
     w->tws = ar.take<char>(trtri_batch_ws_bytes(n, B));
@@ -340,27 +344,32 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     std::vector<int> sel((size_t)2 * Bt, 0);
     int nlisted = 0;
     int *const listv = w.active + Bt;
-    auto send_mask = [&](const std::vector<int> &h) -> vslam_status {
+    std::vector<double> up((size_t)2 * Bt, 0.0);                  // staging: Bt multipliers, then the 2 Bt words of mask and list
+    auto send_mask = [&](const std::vector<int> &h, bool with_lam = false) -> vslam_status {
         std::fill(sel.begin(), sel.end(), 0);
         nlisted = 0;
         for (size_t i = 0; i < h.size(); ++i)
             if (h[i]) { sel[i] = 1; sel[(size_t)Bt + nlisted++] = (int)i; }
-        return h2d(ctx, w.active, sel.data(), sel.size() * sizeof(int));
+        if (!with_lam) return h2d(ctx, w.active, sel.data(), sel.size() * sizeof(int));
+        std::memcpy(up.data(), lam.data(), (size_t)Bt * 8);
+        std::memcpy(up.data() + Bt, sel.data(), sel.size() * sizeof(int));
+        return h2d(ctx, w.lam, up.data(), up.size() * 8);
     };
     auto any = [&](const std::vector<int> &h) { return std::any_of(h.begin(), h.end(), [](int v) { return v != 0; }); };
     // results of bk_dots_kernel and the factorisation flags of all slots
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
         BkDotArgs d;
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2;
-        hipLaunchKernelGGL(bk_dots_kernel, dim3(Bt), dim3(BK_T), 0, s, d, n, w.dots, w.active);
+        hipLaunchKernelGGL(bk_dots_kernel, dim3(Bt), dim3(BK_T), 0, s, d, n, w.dots, w.active, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)4 * Bt * 8));
-        VSLAM_TRY(d2h(ctx, hinfo.data(), w.info, (size_t)Bt * sizeof(int)));
-        return stream_sync(ctx);
+        VSLAM_TRY(stream_sync(ctx));
+        for (int sl = 0; sl < Bt; ++sl) hinfo[sl] = (int)hd[(size_t)4 * sl + 3];
+        return VSLAM_OK;
     };
     // for the slots of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
+    // (the multipliers travel with the mask: send_mask(mask, true) right before)
     auto factor_and_step = [&]() -> vslam_status {
-        VSLAM_TRY(h2d(ctx, w.lam, lam.data(), (size_t)Bt * 8));
         if (nlisted == 0) return VSLAM_OK;
         const bool by_list = chain_trsv && nlisted < Bt;            // launches over the list of slots (the older solve kernel takes masks only)
         const int *selp = by_list ? listv : w.active;
@@ -471,7 +480,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         }
         // ---- trust-region subproblems, src/fmin.cpp:40-131 with l1 > 0 ----
         std::fill(lam.begin(), lam.end(), 0.0);
-        VSLAM_TRY(send_mask(trs));
+        VSLAM_TRY(send_mask(trs, true));
         VSLAM_TRY(factor_and_step());
         VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
         {
@@ -498,7 +507,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 }
             if (!any(m)) break;
             ++trace_steps;
-            VSLAM_TRY(send_mask(m));
+            VSLAM_TRY(send_mask(m, true));
             VSLAM_TRY(factor_and_step());
             for (int sl = 0; sl < Bt; ++sl)
                 if (stop[sl]) m[sl] = 0;
