@@ -78,6 +78,9 @@ size_t trtri_batch_ws_bytes(int n, int batch);
 vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
                                    int batch, void *ws);
 
+// Upper triangle of B(i, j) = A(n-1-i, n-1-j) (transposed: A(n-1-j, n-1-i)) for `batch` n x n matrices (ld n) `stride` apart;
+// what lies below the diagonal tiles of B is not written.
+vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch);
 // Strict lower triangle := transpose of the strict upper triangle (batch matrices strideA apart).
 vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch);
 

@@ -428,14 +428,6 @@ __global__ void matvec_sum_kernel(const double *part, int n, double *y)
     y[r] = acc;
 }
 
-__global__ __launch_bounds__(256) void reverse_kernel(const double *A, int n, double *B, int transposed)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-    if (i >= n) return;
-    const int ri = n - 1 - i, rj = n - 1 - j;
-    B[(size_t)j * n + i] = transposed ? A[(size_t)ri * n + rj] : A[(size_t)rj * n + ri];
-}
-
 size_t newton_ws_bytes(int n)
 {
     const size_t nn = (size_t)n * n;
@@ -576,11 +568,9 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     // ---- posterior: the upper-triangular S with S^T S = H^-1 at the final iterate.  With J the index reversal,
     // J H J = U'^T U' (Cholesky) gives H = M M^T for the upper-triangular M = J U'^T J, hence S = M^-1
     // (S^T S = M^-T M^-1 = H^-1): one factorisation and one triangular inverse, no QR. ----
-    hipLaunchKernelGGL(reverse_kernel, dim3(nb, n), dim3(256), 0, s, w.Hcur, n, w.U, 0);
-    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, 0, 1));
     VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
-    hipLaunchKernelGGL(reverse_kernel, dim3(nb, n), dim3(256), 0, s, w.U, n, c->Hl, 1);           // Hl, W: scratch from here on
-    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, c->Hl, true, 0, 1));                                  // Hl, W: scratch from here on
     VSLAM_TRY(trtri_upper_dev(ctx, c->Hl, n, n, c->W, n, c->tws));
     VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
     VSLAM_TRY(d2h(ctx, mu_post, w.xcur, (size_t)n * 8));

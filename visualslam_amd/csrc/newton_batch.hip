@@ -237,16 +237,6 @@ __global__ __launch_bounds__(BK_T) void bk_log_gaussian_value_kernel(const doubl
     }
 }
 
-// B(i, j) = A(n-1-i, n-1-j), or with `transposed` B(i, j) = A(n-1-j, n-1-i), per instance
-__global__ __launch_bounds__(256) void bk_reverse_kernel(const double *A, int n, double *B, int transposed)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-    if (i >= n) return;
-    const size_t o = (size_t)blockIdx.z * n * n;
-    const int ri = n - 1 - i, rj = n - 1 - j;
-    B[o + (size_t)j * n + i] = transposed ? A[o + (size_t)ri * n + rj] : A[o + (size_t)rj * n + ri];
-}
-
 // B filters and Bt - B further slots in which trust-region subproblems of the same filters are solved ahead
 // (iekf_bank_chunk): the slots beyond B own a factor, a current Hessian and the vectors, nothing else.
 struct BankWs {
@@ -583,12 +573,10 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     std::vector<int> ok(B);
     for (int b = 0; b < B; ++b) ok[b] = stat[b] == 0;
     VSLAM_TRY(send_mask(ok));
-    hipLaunchKernelGGL(bk_reverse_kernel, dim3(nb, n, B), dim3(256), 0, s, w.Hcur, n, w.U, 0);
-    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, nn, B));
     VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), s));
     VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active));
-    hipLaunchKernelGGL(bk_reverse_kernel, dim3(nb, n, B), dim3(256), 0, s, w.U, n, w.Hl, 1);
-    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, w.Hl, true, nn, B));
     VSLAM_TRY(trtri_upper_batch_dev(ctx, w.Hl, n, n, nn, S_post, n, nn, B, w.tws));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mu_post, w.xcur, (size_t)B * n * 8, hipMemcpyDeviceToDevice, s));
     VSLAM_TRY(d2h(ctx, hinfo.data(), w.info, (size_t)B * sizeof(int)));

@@ -687,6 +687,47 @@ vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t 
     return VSLAM_OK;
 }
 
+// Index reversal of symmetric / triangular n x n matrices (ld n, `batch` of them stride apart), upper triangle of the
+// result only (64 x 64 tiles that touch it):  B(i, j) = A(n-1-i, n-1-j), or with `transposed` B(i, j) = A(n-1-j, n-1-i)
+// -- the upper-triangular J U^T J of an upper-triangular U.  The transposed form goes through an LDS tile so that both
+// the reads of A and the writes of B run along columns.
+__global__ __launch_bounds__(256) void reverse_upper_kernel(const double *A, int n, double *B, int transposed, size_t stride)
+{
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    if (i0 > j0 + 63) return;                                     // wholly below the diagonal
+    const double *Ab = A + (size_t)blockIdx.z * stride;
+    double *Bb = B + (size_t)blockIdx.z * stride;
+    const int a = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (!transposed) {
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int i = i0 + a, j = j0 + 4 * p + q;
+            if (i < n && j < n) Bb[(size_t)j * n + i] = Ab[(size_t)(n - 1 - j) * n + (n - 1 - i)];
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {                                // tile[ii][jj] = B(i0 + ii, j0 + jj) = A(n-1-j, n-1-i): rows of A along the lanes
+        const int ii = 4 * p + q, i = i0 + ii, j = j0 + a;
+        tile[ii][a] = (i < n && j < n) ? Ab[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+        const int jj = 4 * p + q, i = i0 + a, j = j0 + jj;
+        if (i < n && j < n) Bb[(size_t)j * n + i] = tile[a][jj];
+    }
+}
+
+vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch)
+{
+    const int T = (n + 63) / 64;
+    hipLaunchKernelGGL(reverse_upper_kernel, dim3(T, T, batch), dim3(256), 0, ctx->stream, A, n, B, transposed ? 1 : 0, stride);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
+}
+
 // The same solves for a bank: matrix m at S + m * strideS, right-hand side and result at rhs / z + m * n (they may be
 // the same vectors), matrices with active[m] == 0 skipped (active may be null; listed: active holds `count` matrix
 // indices instead).  False when the size is outside what
