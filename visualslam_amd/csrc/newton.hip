@@ -569,7 +569,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     // J H J = U'^T U' (Cholesky) gives H = M M^T for the upper-triangular M = J U'^T J, hence S = M^-1
     // (S^T S = M^-T M^-1 = H^-1): one factorisation and one triangular inverse, no QR. ----
     VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, 0, 1));
-    VSLAM_TRY(potrf_upper_dev(ctx, w.U, n, n, w.info));
+    VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, /*zero_lower=*/false));      // the reversal reads the upper tiles only
     VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, c->Hl, true, 0, 1));                                  // Hl, W: scratch from here on
     VSLAM_TRY(trtri_upper_dev(ctx, c->Hl, n, n, c->W, n, c->tws));
     VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));

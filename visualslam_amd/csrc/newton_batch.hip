@@ -575,7 +575,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     VSLAM_TRY(send_mask(ok));
     VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, nn, B));
     VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), s));
-    VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active));
+    VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false));     // the reversal reads the upper tiles only
     VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, w.Hl, true, nn, B));
     VSLAM_TRY(trtri_upper_batch_dev(ctx, w.Hl, n, n, nn, S_post, n, nn, B, w.tws));
     VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mu_post, w.xcur, (size_t)B * n * 8, hipMemcpyDeviceToDevice, s));
