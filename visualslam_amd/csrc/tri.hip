@@ -16,16 +16,17 @@ namespace vslam {
 constexpr int TBK = 64;          // diagonal block of the triangular inverse
 
 // Workgroup b (one wave) inverts the upper-triangular diagonal block b (64 x 64, the last one
-// smaller) of S into the same block of W (zeros below the diagonal).  Lane c owns column
-// c of the inverse and back-substitutes e_c:  x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r];
-// both matrices live in LDS (U read as broadcasts, the inverse lane-contiguous).
+// smaller) of S into the same block of W (zeros below the diagonal).  Lane c owns column c of the inverse -- in
+// registers -- and back-substitutes e_c:  x_r = (delta_rc - sum_{k>r} U[r][k] x_k) / U[r][r], the rows of U as
+// broadcast reads from LDS, four partial sums per row, the pivots' reciprocals taken once; the loops are unrolled
+// completely, so x stays in registers and a row costs its multiply-adds.  The result goes through the same LDS
+// block transposed, so that a column of W is written as one contiguous run.
+constexpr int TDS = TBK + 2;     // row stride of the block in LDS (even: rows are read as pairs)
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS, int n, double *W, int ldW, size_t strideS, size_t strideW)
 {
     S += (size_t)blockIdx.y * strideS;                 // instance blockIdx.y of a batch
     W += (size_t)blockIdx.y * strideW;
-    extern __shared__ double trtri_lds[];
-    double *U = trtri_lds;                        // [TBK][TBK + 1]
-    double *X = trtri_lds + TBK * (TBK + 1);      // [TBK][TBK], X[r][c]
+    __shared__ __align__(16) double U[TBK * TDS];
     const int c = threadIdx.x, j0 = blockIdx.x * TBK, jb = min(TBK, n - j0);
     const double *Sb = S + (size_t)j0 * ldS + j0;
     double *D = W + (size_t)j0 * ldW + j0;
@@ -37,17 +38,25 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double *S, int ldS
             v[j] = (c <= cc && cc < jb) ? Sb[(size_t)cc * ldS + c] : ((c == cc) ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) U[c * (TBK + 1) + cb + j] = v[j];
+        for (int j = 0; j < 16; ++j) U[c * TDS + cb + j] = v[j];
     }
     __syncthreads();
+    const double rinv = 1.0 / U[c * TDS + c];          // lane r: reciprocal of pivot r
+    double x[TBK];
+#pragma unroll
     for (int r = TBK - 1; r >= 0; --r) {
-        const double num = lds_dot_sub((r == c) ? 1.0 : 0.0, U + r * (TBK + 1), 1, X + c, TBK, r + 1, TBK);
-        X[r * TBK + c] = (r <= c) ? num / U[r * (TBK + 1) + r] : 0.0;
+        double s[4] = {(r == c) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = r + 1; k < TBK; ++k) s[k & 3] = fma(-U[r * TDS + k], x[k], s[k & 3]);
+        x[r] = (r <= c) ? ((s[0] + s[1]) + (s[2] + s[3])) * readlane_f64(rinv, r) : 0.0;
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TBK; ++r) U[r * TDS + c] = x[r];        // U is spent: it now holds the inverse, X[r][c]
     __syncthreads();
     // lane = row of the inverse: a column of W is written as one contiguous run
     for (int cc = 0; cc < jb; ++cc)
-        if (c < jb) D[(size_t)cc * ldW + c] = X[c * TBK + cc];
+        if (c < jb) D[(size_t)cc * ldW + c] = U[c * TDS + cc];
 }
 
 __global__ void zero_lower_block_kernel(double *W, int ldW, int n, size_t strideW)
@@ -85,9 +94,7 @@ vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int l
     double *Tmp = ar.take<double>(trtri_tmp_doubles(n, batch));
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, s, W, ldW, n, strideW);
-    const size_t dlds = (size_t)(TBK * (TBK + 1) + TBK * TBK) * 8;
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trtri_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
-    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), dlds, s, S, ldS, n, W, ldW, strideS, strideW);
+    hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), 0, s, S, ldS, n, W, ldW, strideS, strideW);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     // pairs [i0, i0+b) and [i0+b, i0+b+r) of one level: `count` of them `pair_stride` blocks apart (or the bank)
     auto join = [&](int i0, int b, int r, int count) -> vslam_status {
