@@ -188,7 +188,7 @@ vslam_status log_gaussian_dev(vslam_ctx *ctx, const double *x, const double *mu,
     hipLaunchKernelGGL(log_gaussian_value_kernel, dim3(1), dim3(256), 0, s, tmp, S, n, ldS, value, g);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     if (H) {
-        VSLAM_TRY(trtri_upper_dev(ctx, S, n, ldS, Wbuf, n, tws));
+        VSLAM_TRY(trtri_upper_dev(ctx, S, n, ldS, Wbuf, n, tws, /*zero_lower=*/false));      // W enters the product below as a triangular operand
         GemmDesc d;                                                       // H = -W W^T
         d.M = n; d.N = n; d.K = n; d.transA = false; d.transB = true; d.amode = A_UPPER; d.b_upper = true; d.alpha = -1.0;
         d.A = Wbuf; d.lda = n; d.B = Wbuf; d.ldb = n; d.C = H; d.ldc = n;

@@ -71,12 +71,13 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream);
 size_t qr_ws_bytes(int rows, int cols, int batch);
 vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws);
 
-// W = inverse of the upper-triangular S (n x n); strict lower part of W zeroed.
+// W = inverse of the upper-triangular S (n x n); strict lower part of W zeroed (zero_lower = false: only inside the
+// diagonal 64 x 64 blocks -- for a caller that reads W as a triangular operand and saves the pass).
 size_t trtri_ws_bytes(int n);
-vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws);
+vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws, bool zero_lower = true);
 size_t trtri_batch_ws_bytes(int n, int batch);
 vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
-                                   int batch, void *ws);
+                                   int batch, void *ws, bool zero_lower = true);
 
 // Upper triangle of B(i, j) = A(n-1-i, n-1-j) (transposed: A(n-1-j, n-1-i)) for `batch` n x n matrices (ld n) `stride` apart;
 // what lies below the diagonal tiles of B is not written.

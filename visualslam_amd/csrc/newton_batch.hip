@@ -383,7 +383,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         hipLaunchKernelGGL(bk_log_gaussian_value_kernel, dim3(B), dim3(BK_T), 0, s, w.tmp, S, nn, n, w.vp, w.gp, a);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (!prior_ready) {                                               // the prior Hessian does not depend on x
-            VSLAM_TRY(trtri_upper_batch_dev(ctx, S, n, n, nn, w.W, n, nn, B, w.tws));
+            VSLAM_TRY(trtri_upper_batch_dev(ctx, S, n, n, nn, w.W, n, nn, B, w.tws, /*zero_lower=*/false));   // W enters the product below as a triangular operand
             GemmDesc d;                                                   // Hp = -W W^T
             d.M = n; d.N = n; d.K = n; d.transA = false; d.transB = true; d.amode = A_UPPER; d.b_upper = true; d.alpha = -1.0;
             d.A = w.W; d.lda = n; d.strideA = nn; d.B = w.W; d.ldb = n; d.strideB = nn; d.C = w.Hp; d.ldc = n; d.strideC = nn; d.batch = B;

@@ -87,13 +87,13 @@ size_t trtri_batch_ws_bytes(int n, int batch) { return Arena::pad(trtri_tmp_doub
 // matrices: one pair at a time with the matrices as the batch dimension).  The products are large and few instead
 // of a thin one per block column: 2 log2(n / 64) launches on the matrix cores.
 vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int ldS, size_t strideS, double *W, int ldW, size_t strideW,
-                                   int batch, void *ws)
+                                   int batch, void *ws, bool zero_lower)
 {
     Arena ar(ws);
     const int nblk = (n + TBK - 1) / TBK;
     double *Tmp = ar.take<double>(trtri_tmp_doubles(n, batch));
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, s, W, ldW, n, strideW);
+    if (zero_lower) hipLaunchKernelGGL(zero_lower_block_kernel, dim3((n + 255) / 256, n, batch), dim3(256), 0, s, W, ldW, n, strideW);
     hipLaunchKernelGGL(trtri_diag_kernel, dim3(nblk, batch), dim3(64), 0, s, S, ldS, n, W, ldW, strideS, strideW);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     // pairs [i0, i0+b) and [i0+b, i0+b+r) of one level: `count` of them `pair_stride` blocks apart (or the bank)
@@ -125,9 +125,9 @@ vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int l
     return VSLAM_OK;
 }
 
-vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws)
+vslam_status trtri_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, double *W, int ldW, void *ws, bool zero_lower)
 {
-    return trtri_upper_batch_dev(ctx, S, n, ldS, 0, W, ldW, 0, 1, ws);
+    return trtri_upper_batch_dev(ctx, S, n, ldS, 0, W, ldW, 0, 1, ws, zero_lower);
 }
 
 __global__ void scale_kernel(double *z, int n, double scale)
