@@ -80,8 +80,8 @@ vslam_status trtri_upper_batch_dev(vslam_ctx *ctx, const double *S, int n, int l
                                    int batch, void *ws, bool zero_lower = true);
 
 // Upper triangle of B(i, j) = A(n-1-i, n-1-j) (transposed: A(n-1-j, n-1-i)) for `batch` n x n matrices (ld n) `stride` apart;
-// what lies below the diagonal tiles of B is not written.
-vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch);
+// what lies below the diagonal tiles of B is not written.  sym_upper: A is symmetric and only its upper triangle is read.
+vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch, bool sym_upper = false);
 // Strict lower triangle := transpose of the strict upper triangle (batch matrices strideA apart).
 vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t strideA, int batch);
 

@@ -155,27 +155,37 @@ __global__ void bk_axpby_kernel(double a, const double *x, double c, const doubl
     out[e] = a * x[e] + (y ? c * y[e] : 0.0);
 }
 
-// y[b] = H[b] x[b] for the n x n column-major matrices of the selected instances (ld n, matrices n * n apart, vectors
-// n apart): workgroup (rb, row of the grid) takes rows 64 rb ... 64 rb + 63, its four waves every fourth column; a wave
-// reads 64 consecutive rows of a column.  Fixed summation order.
+// y[b] = H[b] x[b] for the symmetric n x n column-major matrices of the selected instances (ld n, matrices n * n apart,
+// vectors n apart), reading only the tiles of 64 x 64 on and above the diagonal: workgroup (rb, row of the grid) takes rows
+// r0 = 64 rb ... r0 + 63.  The columns from r0 on are read as rows of the matrix (its four waves every fourth column, a
+// wave reads 64 consecutive rows of a column); the columns before r0 are taken from the transposed side, H[0 .. r0-1][r]
+// dot x[0 .. r0-1], a wave per column.  Fixed summation order.
 __global__ __launch_bounds__(256) void bk_matvec_kernel(const double *H, int n, const double *x, double *y, const int *active, int listed)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[4][64], left[64];
     const int b = instance_of(active, listed, blockIdx.y);
     if (b < 0) return;
     const double *Hb = H + (size_t)b * n * n, *xb = x + (size_t)b * n;
-    const int r = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, rr = min(r, n - 1);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, r0 = blockIdx.x * 64;
+    const int r = r0 + lane, rr = min(r, n - 1);
     double a0 = 0.0, a1 = 0.0;
-    int c = q;
+    int c = r0 + q;
     for (; c + 4 < n; c += 8) {
         const double v0 = Hb[(size_t)c * n + rr], v1 = Hb[(size_t)(c + 4) * n + rr];
         a0 = fma(v0, xb[c], a0); a1 = fma(v1, xb[c + 4], a1);
     }
     if (c < n) a0 = fma(Hb[(size_t)c * n + rr], xb[c], a0);
-    red[q][threadIdx.x & 63] = a0 + a1;
+    red[q][lane] = a0 + a1;
+    for (int j = q; j < 64; j += 4) {
+        const double *col = Hb + (size_t)min(r0 + j, n - 1) * n;
+        double t = 0.0;
+        for (int i = lane; i < r0; i += 64) t = fma(col[i], xb[i], t);
+        t = wave_sum(t);
+        if (lane == 0) left[j] = t;
+    }
     __syncthreads();
     if (threadIdx.x < 64 && r < n)
-        y[(size_t)b * n + r] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        y[(size_t)b * n + r] = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + left[lane];
 }
 
 // dst[b] = src[b] (count doubles per instance), active instances only
@@ -210,6 +220,22 @@ __global__ void bk_neg_sum_kernel(const double *a, const double *c, double *out,
     if (active && !active[b]) return;
     const size_t base = (size_t)b * count, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[base + i] = -(a[base + i] + c[base + i]);
+}
+
+// out[b] = -(a[b] + c[b]) on the tiles of 64 x 64 on and above the diagonal of n x n column-major matrices (ld n, n * n
+// apart), active instances only: column j down to the end of its diagonal tile.  A workgroup takes 16 columns, a wave
+// every fourth of them.
+__global__ __launch_bounds__(256) void bk_neg_sum_upper_kernel(const double *a, const double *c, double *out, int n, const int *active)
+{
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const size_t base = (size_t)b * n * n;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int j = blockIdx.x * 16 + q; j < min(n, blockIdx.x * 16 + 16); j += 4) {
+        const int rows = min(n, (j / 64 + 1) * 64);
+        const size_t o = base + (size_t)j * n;
+        for (int i = lane; i < rows; i += 64) out[o + i] = -(a[o + i] + c[o + i]);
+    }
 }
 
 // logGaussian value (src/gaussian.hpp:41-45) of every instance from z = S^-T (x - mu); g = -g in place.
@@ -404,7 +430,9 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     auto accept = [&]() {
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.xcur, w.x, (size_t)n, w.active);
         hipLaunchKernelGGL(bk_copy_kernel, dim3(1, B), dim3(256), 0, s, w.gcur, w.g, (size_t)n, w.active);
-        hipLaunchKernelGGL(bk_neg_sum_kernel, dim3(grid_for(nn), B), dim3(256), 0, s, w.Hp, w.Hl, w.Hcur, nn, w.active);      // Hcur = -(Hp + Hl) of the point just evaluated
+        // Hcur = -(Hp + Hl) of the point just evaluated; every reader of Hcur (the factorisation, the product with the
+        // step, the posterior's reversal) takes the tiles on and above the diagonal only
+        hipLaunchKernelGGL(bk_neg_sum_upper_kernel, dim3((n + 15) / 16, B), dim3(256), 0, s, w.Hp, w.Hl, w.Hcur, n, w.active);
     };
     // dst[slot] = src[map[slot]] for the slots whose map entry is not negative
     auto gather = [&](double *dst, const double *src, size_t count, int slots) {
@@ -573,7 +601,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     std::vector<int> ok(B);
     for (int b = 0; b < B; ++b) ok[b] = stat[b] == 0;
     VSLAM_TRY(send_mask(ok));
-    VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, nn, B));
+    VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, nn, B, /*sym_upper=*/true));   // Hcur holds its upper tiles only
     VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)B * sizeof(int), s));
     VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, B, w.info, w.active, /*zero_lower=*/false));     // the reversal reads the upper tiles only
     VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, w.Hl, true, nn, B));

@@ -697,7 +697,8 @@ vslam_status mirror_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, size_t 
 // Index reversal of symmetric / triangular n x n matrices (ld n, `batch` of them stride apart), upper triangle of the
 // result only (64 x 64 tiles that touch it):  B(i, j) = A(n-1-i, n-1-j), or with `transposed` B(i, j) = A(n-1-j, n-1-i)
 // -- the upper-triangular J U^T J of an upper-triangular U.  The transposed form goes through an LDS tile so that both
-// the reads of A and the writes of B run along columns.
+// the reads of A and the writes of B run along columns.  transposed == 2: A is symmetric and only its upper triangle is
+// read (an element below the diagonal of B's diagonal tiles comes from its mirror image).
 __global__ __launch_bounds__(256) void reverse_upper_kernel(const double *A, int n, double *B, int transposed, size_t stride)
 {
     __shared__ double tile[64][65];
@@ -717,7 +718,9 @@ __global__ __launch_bounds__(256) void reverse_upper_kernel(const double *A, int
 #pragma unroll 4
     for (int p = 0; p < 16; ++p) {                                // tile[ii][jj] = B(i0 + ii, j0 + jj) = A(n-1-j, n-1-i): rows of A along the lanes
         const int ii = 4 * p + q, i = i0 + ii, j = j0 + a;
-        tile[ii][a] = (i < n && j < n) ? Ab[(size_t)(n - 1 - i) * n + (n - 1 - j)] : 0.0;
+        const bool flip = transposed == 2 && i > j;
+        const int ci = flip ? j : i, rj = flip ? i : j;
+        tile[ii][a] = (i < n && j < n) ? Ab[(size_t)(n - 1 - ci) * n + (n - 1 - rj)] : 0.0;
     }
     __syncthreads();
 #pragma unroll 4
@@ -727,10 +730,10 @@ __global__ __launch_bounds__(256) void reverse_upper_kernel(const double *A, int
     }
 }
 
-vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch)
+vslam_status reverse_upper_dev(vslam_ctx *ctx, const double *A, int n, double *B, bool transposed, size_t stride, int batch, bool sym_upper)
 {
     const int T = (n + 63) / 64;
-    hipLaunchKernelGGL(reverse_upper_kernel, dim3(T, T, batch), dim3(256), 0, ctx->stream, A, n, B, transposed ? 1 : 0, stride);
+    hipLaunchKernelGGL(reverse_upper_kernel, dim3(T, T, batch), dim3(256), 0, ctx->stream, A, n, B, sym_upper ? 2 : transposed ? 1 : 0, stride);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
