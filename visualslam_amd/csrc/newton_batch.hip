@@ -206,6 +206,21 @@ __global__ void bk_gather_kernel(double *dst, const double *src, size_t count, c
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dst[to + i] = src[base + i];
 }
 
+// the same for the tiles of 64 x 64 on and above the diagonal of n x n column-major matrices (ld n, n * n apart); columns
+// are dealt as in bk_neg_sum_upper_kernel
+__global__ __launch_bounds__(256) void bk_gather_upper_kernel(double *dst, const double *src, int n, const int *src_of)
+{
+    const int s = blockIdx.y, from = src_of[s];
+    if (from < 0) return;
+    const size_t to = (size_t)s * n * n, base = (size_t)from * n * n;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int j = blockIdx.x * 16 + q; j < min(n, blockIdx.x * 16 + 16); j += 4) {
+        const int rows = min(n, (j / 64 + 1) * 64);
+        const size_t o = (size_t)j * n;
+        for (int i = lane; i < rows; i += 64) dst[to + o + i] = src[base + o + i];
+    }
+}
+
 // out[b] = a[b] - c[b] / out[b] = -(a[b] + c[b]) over `count` doubles per instance, active instances only
 __global__ void bk_sub_kernel(const double *a, const double *c, double *out, size_t count, const int *active)
 {
@@ -490,7 +505,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 }
                 VSLAM_TRY(send_map());
                 VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info + B, 0, (size_t)(Bt - B) * sizeof(int), s));
-                gather(w.Hcur, w.Hcur, nn, Bt);
+                hipLaunchKernelGGL(bk_gather_upper_kernel, dim3((n + 15) / 16, Bt), dim3(256), 0, s, w.Hcur, w.Hcur, n, w.map);   // Hcur holds its upper tiles only
                 gather(w.gcur, w.gcur, (size_t)n, Bt);
                 gather(w.xcur, w.xcur, (size_t)n, Bt);
                 VSLAM_HIP_TRY(ctx, hipGetLastError());

@@ -715,15 +715,18 @@ __global__ __launch_bounds__(256) void reverse_upper_kernel(const double *A, int
         }
         return;
     }
-#pragma unroll 4
+    double v[16];                                                 // all of a thread's reads in flight together
+#pragma unroll
     for (int p = 0; p < 16; ++p) {                                // tile[ii][jj] = B(i0 + ii, j0 + jj) = A(n-1-j, n-1-i): rows of A along the lanes
-        const int ii = 4 * p + q, i = i0 + ii, j = j0 + a;
+        const int i = i0 + 4 * p + q, j = j0 + a;
         const bool flip = transposed == 2 && i > j;
         const int ci = flip ? j : i, rj = flip ? i : j;
-        tile[ii][a] = (i < n && j < n) ? Ab[(size_t)(n - 1 - ci) * n + (n - 1 - rj)] : 0.0;
+        v[p] = (i < n && j < n) ? Ab[(size_t)(n - 1 - ci) * n + (n - 1 - rj)] : 0.0;
     }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tile[4 * p + q][a] = v[p];
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int p = 0; p < 16; ++p) {
         const int jj = 4 * p + q, i = i0 + a, j = j0 + jj;
         if (i < n && j < n) Bb[(size_t)j * n + i] = tile[a][jj];
