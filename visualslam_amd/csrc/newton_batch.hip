@@ -428,9 +428,8 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
             GemmDesc d;                                                   // Hp = -W W^T
             d.M = n; d.N = n; d.K = n; d.transA = false; d.transB = true; d.amode = A_UPPER; d.b_upper = true; d.alpha = -1.0;
             d.A = w.W; d.lda = n; d.strideA = nn; d.B = w.W; d.ldb = n; d.strideB = nn; d.C = w.Hp; d.ldc = n; d.strideC = nn; d.batch = B;
-            d.c_upper = true;                                             // symmetric: upper tiles, then mirrored
+            d.c_upper = true;                                             // symmetric: the upper tiles are all accept() reads
             VSLAM_TRY(gemm_f64(ctx, d));
-            VSLAM_TRY(mirror_upper_dev(ctx, w.Hp, n, n, nn, B));
             prior_ready = true;
         }
         VSLAM_TRY(launch_point_loglik(ctx, k, B, n, w.x, n, y, 2 * (size_t)L, vis, L, sigma, w.vl, w.gl, n, w.Hl, n, nn, nullptr, a));
