@@ -170,18 +170,25 @@ __global__ __launch_bounds__(256) void bk_matvec_kernel(const double *H, int n, 
     const int r = r0 + lane, rr = min(r, n - 1);
     double a0 = 0.0, a1 = 0.0;
     int c = r0 + q;
+#pragma unroll 4
     for (; c + 4 < n; c += 8) {
         const double v0 = Hb[(size_t)c * n + rr], v1 = Hb[(size_t)(c + 4) * n + rr];
         a0 = fma(v0, xb[c], a0); a1 = fma(v1, xb[c + 4], a1);
     }
     if (c < n) a0 = fma(Hb[(size_t)c * n + rr], xb[c], a0);
     red[q][lane] = a0 + a1;
-    for (int j = q; j < 64; j += 4) {
-        const double *col = Hb + (size_t)min(r0 + j, n - 1) * n;
-        double t = 0.0;
-        for (int i = lane; i < r0; i += 64) t = fma(col[i], xb[i], t);
-        t = wave_sum(t);
-        if (lane == 0) left[j] = t;
+    for (int j = q; j < 64; j += 16) {                            // four of the wave's columns together
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = lane; i < r0; i += 64) {
+            const double xi = xb[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = fma(Hb[(size_t)min(r0 + j + 4 * e, n - 1) * n + i], xi, t[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double v = wave_sum(t[e]);
+            if (lane == 0) left[j + 4 * e] = v;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64 && r < n)
@@ -213,11 +220,16 @@ __global__ __launch_bounds__(256) void bk_gather_upper_kernel(double *dst, const
     const int s = blockIdx.y, from = src_of[s];
     if (from < 0) return;
     const size_t to = (size_t)s * n * n, base = (size_t)from * n * n;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int j = blockIdx.x * 16 + q; j < min(n, blockIdx.x * 16 + 16); j += 4) {
-        const int rows = min(n, (j / 64 + 1) * 64);
-        const size_t o = (size_t)j * n;
-        for (int i = lane; i < rows; i += 64) dst[to + o + i] = src[base + o + i];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, j0 = blockIdx.x * 16;
+    const int rows = min(n, (j0 / 64 + 1) * 64);
+#pragma unroll 2
+    for (int i = lane; i < rows; i += 64) {
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = src[base + (size_t)min(j0 + q + 4 * e, n - 1) * n + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j0 + q + 4 * e < n) dst[to + (size_t)(j0 + q + 4 * e) * n + i] = v[e];
     }
 }
 
@@ -245,11 +257,19 @@ __global__ __launch_bounds__(256) void bk_neg_sum_upper_kernel(const double *a, 
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     const size_t base = (size_t)b * n * n;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int j = blockIdx.x * 16 + q; j < min(n, blockIdx.x * 16 + 16); j += 4) {
-        const int rows = min(n, (j / 64 + 1) * 64);
-        const size_t o = base + (size_t)j * n;
-        for (int i = lane; i < rows; i += 64) out[o + i] = -(a[o + i] + c[o + i]);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, j0 = blockIdx.x * 16;
+    const int rows = min(n, (j0 / 64 + 1) * 64);                 // the 16 columns lie in one tile column
+#pragma unroll 2
+    for (int i = lane; i < rows; i += 64) {
+        double v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                             // a wave's four columns together: eight reads in flight
+            const size_t o = base + (size_t)min(j0 + q + 4 * e, n - 1) * n + i;
+            v[e] = -(a[o] + c[o]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j0 + q + 4 * e < n) out[base + (size_t)(j0 + q + 4 * e) * n + i] = v[e];
     }
 }
 
