@@ -59,3 +59,49 @@ def rel_err(a, b, floor=None):
     if scale == 0:
         scale = 1.0
     return float(np.max(np.abs(a - b)) / scale) if a.size else 0.0
+
+
+# ---- per-landmark comparison (the parity statement: "per-landmark log-likelihood / gradient / Hessian within 1e-9
+# relative") ----
+# A block is one landmark's piece of an output: its value term, its 3-gradient, its 3 x 3 diagonal block, one of its
+# two 3 x 3 cross blocks with the pose, its contribution to a 3-piece of the pose gradient or to a 3 x 3 piece of the
+# 6 x 6 pose block.  The error of a block is taken relative to THAT block's largest reference entry.  Absolute floor:
+# a block whose largest entry is below BLOCK_FLOOR times the largest block of its kind is measured against that floor
+# instead (its entries are differences of terms of the larger size and carry their rounding); a block that is exactly
+# zero in the reference (culled or invisible landmark) must be exactly zero.
+BLOCK_FLOOR = 1e-6
+
+
+def block_errs(got, ref, floor_frac=BLOCK_FLOOR):
+    """got, ref: (L, ...) arrays of per-landmark blocks.  Returns (worst relative error, index of the worst block);
+    asserts exact zeros where the reference block is exactly zero."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    L = ref.shape[0]
+    g2, r2 = got.reshape(L, -1), ref.reshape(L, -1)
+    scale = np.max(np.abs(r2), axis=1)
+    zero = scale == 0.0
+    assert not g2[zero].any(), "a block that is exactly zero in the reference must be exactly zero"
+    top = float(scale.max()) if L else 0.0
+    if top == 0.0:
+        return 0.0, -1
+    err = np.max(np.abs(g2 - r2), axis=1) / np.maximum(scale, floor_frac * top)
+    j = int(np.argmax(err))
+    return float(err[j]), j
+
+
+def oracle_per_landmark(ocam, x, y, visible, sigma, flavour="dual"):
+    """Each landmark's term on its own from the CPU oracle: the term of landmark j depends on the pose eta = x[6:12]
+    and r_j only, so it is evaluated on the 15-state [0 (6), eta, r_j].  Returns ell (L), g9 (L, 9), H9 (L, 9, 9),
+    code (L); the 9 variables are (rCNn, Theta, r_j)."""
+    from oracle import pyoracle as orc
+    fn = orc.point_loglik_dual_sparse if flavour == "dual" else orc.point_loglik_analytic
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    L = (x.size - 12) // 3
+    ell, g9, H9, code = np.zeros(L), np.zeros((L, 9)), np.zeros((L, 9, 9)), np.zeros(L, dtype=np.int32)
+    xj = np.zeros(15)
+    xj[6:12] = x[6:12]
+    for j in range(L):
+        xj[12:15] = x[12 + 3 * j:15 + 3 * j]
+        v, g, H, c = fn(xj, y[2 * j:2 * j + 2], [visible[j]], ocam, sigma)
+        ell[j], g9[j], H9[j], code[j] = v, g[6:], H[6:, 6:], c[0]
+    return ell, g9, H9, code

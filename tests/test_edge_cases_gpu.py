@@ -143,3 +143,72 @@ def test_bundle_empty_visibility_and_single_landmark(ctx, gcam, ocam):
     assert np.array_equal(code, c0)
     if c0[0] != 0:
         assert v == 0.0 and not g.any() and not H.any()
+
+
+def test_empty_map_frame(ctx, gcam, ocam):
+    """The frames before the first landmark: the state is the 12 pose / velocity entries alone.  The reference still runs
+    the measurement update on every frame (src/SLAM.cpp:489-495); pointLogLikelihood loops over param.landmarks.size()
+    landmarks (src/model.cpp:392), none, so the likelihood is 0 with zero gradient and Hessian -- the case
+    test/src/measurementModel.cpp:462-519 sets up ("points" with an empty landmark list) -- and the update returns the
+    prior.  Checked against the CPU oracle on the same inputs."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    rng = np.random.default_rng(12)
+    n = 12
+    mu = np.concatenate([0.1 * rng.standard_normal(6), [0.0, -5.0, -1.8, -1.57, 3.14, 0.0]])
+    S = np.triu(0.02 * rng.standard_normal((n, n)), 1) + np.diag(np.concatenate([np.full(6, 0.1), np.full(6, 0.001)]))
+    S = np.asfortranarray(S)
+    none, novis = np.zeros(0), np.zeros(0, np.uint8)
+    # PointLogLikelihood x3 (src/model.cpp:408-437)
+    v, g, H, code = api.point_loglik(ctx, gcam, mu, none, novis, 7.0)
+    v0, g0, H0, _ = orc.point_loglik_dual_sparse(mu, none, novis, ocam, 7.0)
+    assert v == 0.0 and v0 == 0.0 and code.size == 0
+    assert g.shape == (n,) and H.shape == (n, n) and not g.any() and not H.any() and not g0.any() and not H0.any()
+    v, _, _, _ = api.point_loglik(ctx, gcam, mu, none, novis, 7.0, want_g=False, want_H=False)
+    assert v == 0.0
+    # the strided-batch device entry, three empty maps
+    dev = torch.device("cuda:0")
+    xs = torch.tensor(np.stack([mu, mu + 1.0, mu - 1.0]), device=dev)
+    empty_y = torch.zeros((3, 0), dtype=torch.float64, device=dev)
+    empty_v = torch.zeros((3, 0), dtype=torch.uint8, device=dev)
+    val = torch.full((3,), float("nan"), dtype=torch.float64, device=dev)
+    gb = torch.full((3, n), float("nan"), dtype=torch.float64, device=dev)
+    Hb = torch.full((3, n, n), float("nan"), dtype=torch.float64, device=dev)
+    api.point_loglik_batch_dev(ctx, gcam, n, xs, empty_y, empty_v, 7.0, val, gb, Hb)
+    torch.cuda.synchronize()
+    assert not val.cpu().numpy().any() and not gb.cpu().numpy().any() and not Hb.cpu().numpy().any()
+    # CostJointDensity (src/gaussian.hpp:455-466): the prior alone
+    x = mu + S.T @ (0.3 * rng.standard_normal(n))
+    V, gc, Hc = api.cost_joint_density(ctx, gcam, x, mu, S, none, novis, 7.0)
+    lp, gp, Hp = orc.log_gaussian(x, mu, S)
+    assert abs(V + lp) <= 1e-12 * abs(lp) and rel_err(gc, -gp) <= 1e-9 and rel_err(Hc, -Hp) <= 1e-9
+    # measurementUpdateIEKF (src/gaussian.hpp:469-532): posterior = prior, on both trust-region routes and in a bank
+    ret0, mup0, Sp0, it0, ev0 = orc.measurement_update_iekf(mu, S, none, novis, ocam, 7.0)
+    assert ret0 == 0 and np.abs(mup0 - mu).max() <= 1e-12
+    for solver in (api.TRS_EIG, api.TRS_CHOLESKY):
+        ctx.set_trs_solver(solver)
+        try:
+            ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, none, novis, 7.0)
+        finally:
+            ctx.set_trs_solver(api.TRS_CHOLESKY)
+        assert ctx.last_trs_route() == solver
+        assert (ret, iters, evals) == (ret0, it0, ev0)
+        assert np.abs(mup - mu).max() <= 1e-12
+        assert not np.tril(Sp, -1).any()
+        assert rel_err(Sp.T @ Sp, S.T @ S) <= 1e-9 and rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-9
+    mub = torch.tensor(np.stack([mu, mu + 0.5]), device=dev)
+    Sb = torch.tensor(np.stack([np.ascontiguousarray(S.T)] * 2), device=dev)
+    mpb, Spb = torch.empty_like(mub), torch.empty_like(Sb)
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mub, Sb, empty_y[:2], empty_v[:2], 7.0, mpb, Spb)
+    torch.cuda.synchronize()
+    assert not status.any() and not code.any()
+    assert np.abs(mpb.cpu().numpy() - mub.cpu().numpy()).max() <= 1e-12
+    for b in range(2):
+        S1 = Spb[b].cpu().numpy().T
+        assert rel_err(S1.T @ S1, S.T @ S) <= 1e-9
+    # affineTransform through the bundle (src/gaussian.hpp:85-131): a 0-dimensional predicted measurement
+    muy, Syy, codes = api.affine_bundle(ctx, gcam, mu, S)
+    assert muy.size == 0 and Syy.size == 0 and codes.size == 0
+    h, SR, Cm, codes = api.bundle_measure(ctx, gcam, mu)
+    assert h.size == 0 and Cm.shape == (0, n)

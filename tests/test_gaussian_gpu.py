@@ -141,18 +141,31 @@ def test_cost_joint_density(ctx, gcam, ocam, L, seed):
     assert rel_err(g, -(gp + gl)) <= TOL and rel_err(H, -(Hp + Hl)) <= TOL
 
 
-@pytest.mark.parametrize("solver", ["eig", "cholesky"])
-@pytest.mark.parametrize("L,seed", [(2, 41), (5, 41), (20, 7), (50, 1023)])
-def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
-    """measurementUpdateIEKF (gaussian.hpp:469-532) as called at SLAM.cpp:492.  The
-    posterior mean must match the oracle's; the posterior square-root factor is
-    compared through S^T S and |diag S| because its row signs follow the
-    eigenvector signs of the host eigensolver (the reference has the same
-    dependence on Eigen's SelfAdjointEigenSolver).  Both routes are checked: "eig"
-    restates the reference's host loop, "cholesky" runs the same iteration on the device
-    from Cholesky factors; iteration and evaluation counts must agree with the oracle
-    for both."""
+_ORACLE_UPDATES = {}
+
+
+def _oracle_update(ocam, L, seed):
+    """The CPU restatement's update of Scene(L, seed), computed once per session (5.7 s at 150 landmarks)."""
     from oracle import pyoracle as orc
+    from visualslam_amd import synthetic as syn
+    if (L, seed) not in _ORACLE_UPDATES:
+        sc = syn.Scene(L, seed)
+        _ORACLE_UPDATES[(L, seed)] = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
+    return _ORACLE_UPDATES[(L, seed)]
+
+
+@pytest.mark.parametrize("solver", ["eig", "cholesky"])
+@pytest.mark.parametrize("L,seed", [(2, 41), (5, 41), (20, 7), (50, 1023), (150, 3)])
+def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
+    """measurementUpdateIEKF (gaussian.hpp:469-532) as called at SLAM.cpp:492, up to the 150-landmark
+    configuration (state dimension 462).  The posterior mean must match the oracle's; the posterior
+    square-root factor is compared through S^T S and |diag S| because its row signs follow the
+    eigenvector signs of the host eigensolver (the reference has the same dependence on Eigen's
+    SelfAdjointEigenSolver).  Both routes are checked: "eig" restates the reference's host loop and must
+    reproduce the oracle's iteration and evaluation counts; "cholesky" (the default) runs the same iteration
+    on the device from Cholesky factors: its counts must equal the oracle's up to 50 landmarks and may differ
+    by at most two at 150, where the last iterations are rejected steps decided by rounding noise (then the
+    means are compared against the posterior spread)."""
     from visualslam_amd import api, synthetic as syn
     sc = syn.Scene(L, seed)
     ctx.set_trs_solver(api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
@@ -161,14 +174,20 @@ def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     finally:
         ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
     assert ctx.last_trs_route() == (api.TRS_EIG if solver == "eig" else api.TRS_CHOLESKY)
-    ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(sc.x, sc.S, sc.y, sc.visible, ocam, sc.sigma)
+    ret0, mup0, Sp0, iters0, evals0 = _oracle_update(ocam, L, seed)
     assert ret == 0 and ret0 == 0
-    assert (iters, evals) == (iters0, evals0)
-    scale = np.abs(np.diag(Sp0 @ Sp0.T)) ** 0.5 + 1e-300
-    assert np.max(np.abs(mup - mup0) / np.maximum(np.abs(mup0), sc.diag)) <= 1e-7
+    if solver == "eig" or L <= 50:
+        assert (iters, evals) == (iters0, evals0)
+    else:
+        assert abs(iters - iters0) <= 2 and abs(evals - evals0) <= 2
     assert not np.tril(Sp, -1).any()
-    assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-7
-    assert rel_err(np.abs(np.diag(Sp)), np.abs(np.diag(Sp0))) <= 1e-7
+    if (iters, evals) == (iters0, evals0):
+        assert np.max(np.abs(mup - mup0) / np.maximum(np.abs(mup0), sc.diag)) <= 1e-7
+        assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-7
+        assert rel_err(np.abs(np.diag(Sp)), np.abs(np.diag(Sp0))) <= 1e-7
+    else:
+        assert np.linalg.norm(np.linalg.solve(Sp0.T, mup - mup0)) <= 1e-6
+        assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-6
     # the update must not increase the cost and the posterior information matches the Hessian at the optimum
     V0, _, _ = api.cost_joint_density(ctx, gcam, sc.x, sc.x, sc.S, sc.y, sc.visible, sc.sigma)
     V1, g1, H1 = api.cost_joint_density(ctx, gcam, mup, sc.x, sc.S, sc.y, sc.visible, sc.sigma)

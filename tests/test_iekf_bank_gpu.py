@@ -61,12 +61,13 @@ def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
         ctx.set_trs_solver(api.TRS_CHOLESKY)
 
 
-@pytest.mark.parametrize("L,B,perturb", [(5, 4, False), (20, 3, False), (5, 4, True), (20, 3, True)])
+@pytest.mark.parametrize("L,B,perturb", [(5, 4, False), (20, 3, False), (5, 4, True), (20, 3, True), (150, 3, True)])
 def test_bank_matches_the_cpu_restatement(ctx, gcam, ocam, L, B, perturb):
     """The bank against the CPU restatement of measurementUpdateIEKF (eigenvalue trust-region route, as the
     reference runs it), filter by filter: same return code, posterior mean to 1e-9 of its largest entry and
     S^T S to 1e-9 relative where the iteration counts agree (they must for the five-landmark filters started at
-    the scene's own mean).  Elsewhere the last iterations are decided by rounding (|p.g| < 2 eps, rho of steps
+    the scene's own mean), up to the 150-landmark configuration (state dimension 462).  The counts never differ by
+    more than four.  Elsewhere the last iterations are decided by rounding (|p.g| < 2 eps, rho of steps
     the cost no longer resolves): the counts may differ and the results are compared against the posterior spread."""
     import torch
     from oracle import pyoracle as orc
@@ -87,6 +88,7 @@ def test_bank_matches_the_cpu_restatement(ctx, gcam, ocam, L, B, perturb):
         m1 = mup[b].cpu().numpy()
         S1 = Sp[b].cpu().numpy().T
         assert code[b] == ret
+        assert abs(int(iters[b]) - it0) <= 4
         if not perturb and L == 5:
             assert int(iters[b]) == it0
         if int(iters[b]) == it0:

@@ -257,9 +257,11 @@ extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *
                                             int n, int ldS, int layout, double *muy, double *Syy, int ldSyy, int32_t *code)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!mux || !Sxx || !muy || !Syy) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0 || ldS < n) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: n=%d is not 12+3L or ldS < n", n);
+    if (n < 12 || (n - 12) % 3 != 0 || ldS < n) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: n=%d is not 12+3L or ldS < n", n);
     if (layout != VSLAM_LAYOUT_COMPAT && layout != VSLAM_LAYOUT_STRICT) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: bad layout %d", layout);
+    if (!mux || !Sxx) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
+    if (n == 12) return VSLAM_OK;        // a map without landmarks: the predicted measurement has no entries (muy, Syy are 0-dimensional)
+    if (!muy || !Syy) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
     const int L = (n - 12) / 3, m = 2 * L, rows = n + m;
     if (ldSyy < m) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: ldSyy=%d < %d", ldSyy, m);
     CamK k;
@@ -291,10 +293,12 @@ extern "C" vslam_status vslam_affine_bundle_batch_dev(vslam_ctx *ctx, const vsla
                                                       int batch, int layout, double *muy, double *Syy, int32_t *code)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!mux || !Sxx || !muy || !Syy) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: n=%d is not 12+3L", n);
+    if (n < 12 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: n=%d is not 12+3L", n);
     if (layout != VSLAM_LAYOUT_COMPAT && layout != VSLAM_LAYOUT_STRICT) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: bad layout %d", layout);
     if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "affine_bundle: batch=%d out of range", batch);
+    if (!mux || !Sxx) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
+    if (n == 12) return VSLAM_OK;        // maps without landmarks: nothing to predict
+    if (!muy || !Syy) return fail(ctx, VSLAM_ERR_ARG, "affine_bundle: null pointer");
     const int L = (n - 12) / 3, m = 2 * L, rows = n + m;
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
@@ -416,8 +420,9 @@ extern "C" vslam_status vslam_cost_joint_density(vslam_ctx *ctx, const vslam_cam
                                                  double *value, double *g, double *H)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!x || !mu || !S || !y || !visible || !value || !g || !H) return fail(ctx, VSLAM_ERR_ARG, "cost_joint_density: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0 || ldS < n) return fail(ctx, VSLAM_ERR_SHAPE, "cost_joint_density: n=%d is not 12+3L or ldS < n", n);
+    if (n < 12 || (n - 12) % 3 != 0 || ldS < n) return fail(ctx, VSLAM_ERR_SHAPE, "cost_joint_density: n=%d is not 12+3L or ldS < n", n);
+    // n = 12: no landmark yet, the likelihood is the empty sum (src/model.cpp:392) and y / visible have no entries
+    if (!x || !mu || !S || !value || !g || !H || (n > 12 && (!y || !visible))) return fail(ctx, VSLAM_ERR_ARG, "cost_joint_density: null pointer");
     if (!(sigma > 0.0)) return fail(ctx, VSLAM_ERR_ARG, "cost_joint_density: sigma must be positive");
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));

@@ -162,8 +162,10 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
                                                       int32_t *fmin_code, int32_t *iters, int32_t *cost_evals)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!mu || !S || !y || !visible || !mu_post || !S_post) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0 || ldS < n || ldSp < n) return fail(ctx, VSLAM_ERR_SHAPE, "measurement_update_iekf: n=%d is not 12+3L or ld < n", n);
+    // n = 12: the frames before the first landmark; the reference runs the update on every frame (src/SLAM.cpp:489-495)
+    // with an empty likelihood (src/model.cpp:392), which returns the prior
+    if (n < 12 || (n - 12) % 3 != 0 || ldS < n || ldSp < n) return fail(ctx, VSLAM_ERR_SHAPE, "measurement_update_iekf: n=%d is not 12+3L or ld < n", n);
+    if (!mu || !S || !mu_post || !S_post || (n > 12 && (!y || !visible))) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf: null pointer");
     if (!(sigma > 0.0)) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf: sigma must be positive");
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));

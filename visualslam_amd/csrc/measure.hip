@@ -208,8 +208,9 @@ __global__ __launch_bounds__(kThreads) void single_measure_kernel(CamK cam, cons
 vslam_status launch_bundle_measure(vslam_ctx *ctx, const CamK &cam, const double *x, int n, int layout,
                                    double *h, double *SR, double *C, int32_t *code)
 {
-    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "bundle_measure: n=%d is not 12+3L with L>=1", n);
+    if (n < 12 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "bundle_measure: n=%d is not 12+3L", n);
     if (layout != VSLAM_LAYOUT_COMPAT && layout != VSLAM_LAYOUT_STRICT) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure: bad layout %d", layout);
+    if (n == 12) return VSLAM_OK;        // a map without landmarks: the bundle's loop (src/measurementPointLandmark.cpp:61) is empty, h / SR / C have no entries
     BundleArgs a;
     a.x = x; a.h = h; a.SR = SR; a.C = C; a.code = code; a.n = n; a.L = (n - 12) / 3; a.layout = layout;
     int P = (a.L + 2047) / 2048;
@@ -252,8 +253,8 @@ extern "C" vslam_status vslam_bundle_measure(vslam_ctx *ctx, const vslam_camera 
                                              int layout, double *h, double *SR, double *C, int32_t *code)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!x || !h) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "bundle_measure: n=%d is not 12+3L with L>=1", n);
+    if (n < 12 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "bundle_measure: n=%d is not 12+3L", n);
+    if (!x || (n > 12 && !h)) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure: null pointer");
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -280,7 +281,7 @@ extern "C" vslam_status vslam_bundle_measure_dev(vslam_ctx *ctx, const vslam_cam
                                                  double *h, double *SR, double *C, int32_t *code)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!x || !h) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure_dev: null pointer");
+    if (!x || (n > 12 && !h)) return fail(ctx, VSLAM_ERR_ARG, "bundle_measure_dev: null pointer");
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));

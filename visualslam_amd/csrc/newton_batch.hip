@@ -662,8 +662,9 @@ extern "C" vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, 
                                                                 double *S_post, int32_t *fmin_code, int32_t *iters, int32_t *status)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!mu || !S || !y || !visible || !mu_post || !S_post) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf_batch: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0 || batch < 1) return fail(ctx, VSLAM_ERR_SHAPE, "measurement_update_iekf_batch: n=%d is not 12+3L or batch=%d", n, batch);
+    // n = 12: filters whose maps hold no landmark yet (empty likelihood, src/model.cpp:392; the update returns the prior)
+    if (n < 12 || (n - 12) % 3 != 0 || batch < 1) return fail(ctx, VSLAM_ERR_SHAPE, "measurement_update_iekf_batch: n=%d is not 12+3L or batch=%d", n, batch);
+    if (!mu || !S || !mu_post || !S_post || (n > 12 && (!y || !visible))) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf_batch: null pointer");
     if (!(sigma > 0.0)) return fail(ctx, VSLAM_ERR_ARG, "measurement_update_iekf_batch: sigma must be positive");
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));

@@ -417,8 +417,11 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
                                              double *value, double *g, size_t sg, double *H, int ldH, size_t sH,
                                              int32_t *code, const int *active, double *static_scratch)
 {
-    if (!x || !y || !vis || !value) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null input/value pointer");
-    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L with L>=1", n);
+    // n = 12 is the map without a landmark yet (the reference evaluates the likelihood on every frame, src/SLAM.cpp:489-495,
+    // and its loop over param.landmarks, src/model.cpp:392, is then empty): value 0, zero gradient and Hessian; y and
+    // visible have no entries and may be null
+    if (n < 12 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L", n);
+    if (!x || !value || (n > 12 && (!y || !vis))) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null input/value pointer");
     if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: batch=%d out of range", batch);
     if (H && !g) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: H requested without g");
     if (H && ldH < n) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: ldH=%d < n=%d", ldH, n);
@@ -433,7 +436,7 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
     const int panels = (a.L + a.P - 1) / a.P;
     dim3 block(kThreads);
     // With the static scratch every Hessian goes through the two-launch form (the one that needs scratch).
-    const bool two_launch = H && ldH == n && (static_scratch || (size_t)batch * n * n * 8 >= ((size_t)32 << 20));
+    const bool two_launch = H && ldH == n && a.L > 0 && (static_scratch || (size_t)batch * n * n * 8 >= ((size_t)32 << 20));
     if (two_launch) {
         const int slices = (int)(((size_t)n * n * 8 + 127 + kSliceBytes - 1) / kSliceBytes) + 1;
         TermsArgs t;
@@ -546,8 +549,8 @@ extern "C" vslam_status vslam_point_loglik(vslam_ctx *ctx, const vslam_camera *c
                                            double *value, double *g, double *H, int ldH, int32_t *code)
 {
     if (!ctx) return VSLAM_ERR_ARG;
-    if (!x || !y || !visible || !value) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null pointer");
-    if (n < 15 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L with L>=1", n);
+    if (n < 12 || (n - 12) % 3 != 0) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: n=%d is not 12+3L", n);
+    if (!x || !value || (n > 12 && (!y || !visible))) return fail(ctx, VSLAM_ERR_ARG, "point_loglik: null pointer");
     if (H && ldH < n) return fail(ctx, VSLAM_ERR_SHAPE, "point_loglik: ldH=%d < n=%d", ldH, n);
     CamK k;
     VSLAM_TRY(resolve_camera(ctx, cam, &k));
