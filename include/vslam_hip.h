@@ -91,6 +91,20 @@ int vslam_has_device_code(void);
  * <distortion_coefficients>, <flag>, <imageSize>). */
 vslam_status vslam_camera_from_xml(const char *path, vslam_camera *cam);
 
+/* ---- gray frames on disk (PGM) ----
+ * The reference takes its frames from cv::VideoCapture / cv::imread (src/SLAM.cpp:236, src/main.cpp:60-70) and hands
+ * detectAndDrawORB a cv::Mat (src/SLAM.cpp:349); OpenCV is not part of this library, so a frame crosses the
+ * boundary as plain 8-bit gray rows and its file format is binary PGM ("P5": magic, width, height, maxval <= 255
+ * as decimal text separated by white space or '#' comments, one white-space byte, then width * height bytes).
+ * Host only.  vslam_pgm_info reads the header; vslam_pgm_read fills gray[0 .. w*h) row by row (cap = its size in
+ * bytes; VSLAM_ERR_CAPACITY when too small).  A file that is not P5, has maxval > 255 (16-bit samples:
+ * VSLAM_ERR_UNSUPPORTED), a zero / oversized (> 65536) dimension or fewer bytes than the header promises is
+ * VSLAM_ERR_IO and leaves gray untouched beyond what was read. */
+vslam_status vslam_pgm_info(const char *path, int32_t *w, int32_t *h, int32_t *maxval);
+vslam_status vslam_pgm_read(const char *path, uint8_t *gray, size_t cap, int32_t *w, int32_t *h);
+/* Writes w x h gray rows (row stride `stride` bytes) as P5 with maxval 255. */
+vslam_status vslam_pgm_write(const char *path, const uint8_t *gray, int w, int h, int stride);
+
 /* ---- projection ----
  * worldToPixel<double>, src/cameraModel.hpp:32-216, for landmarks j0..j0+L-1
  * of state x (n = 12 + 3*nLandmarks).  px[2L]; code[L] in {0,1,2}. Culled

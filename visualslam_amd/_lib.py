@@ -101,6 +101,9 @@ def _declare(L):
         "vslam_ctx_set_kernel_timing": [_vp, C.c_int],
         "vslam_ctx_last_point_loglik_times": [_vp, _vp, _vp],
         "vslam_camera_from_xml": [C.c_char_p, C.POINTER(Camera)],
+        "vslam_pgm_info": [C.c_char_p, _vp, _vp, _vp],
+        "vslam_pgm_read": [C.c_char_p, _vp, _sz, _vp, _vp],
+        "vslam_pgm_write": [C.c_char_p, _vp, _i, _i, _i],
         "vslam_project": [_vp, C.POINTER(Camera), _vp, _i, _i, _i, _vp, _vp],
         "vslam_bundle_measure": [_vp, C.POINTER(Camera), _vp, _i, _i, _vp, _vp, _vp, _vp],
         "vslam_bundle_measure_dev": [_vp, C.POINTER(Camera), _vp, _i, _i, _vp, _vp, _vp, _vp],

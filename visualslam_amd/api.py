@@ -80,6 +80,21 @@ def camera_from_xml(path):
     return cam
 
 
+def read_pgm(path):
+    """A binary PGM (P5, 8-bit) as an (h, w) uint8 array, through the library's reader."""
+    L = _lib.lib()
+    dims = np.zeros(3, dtype=np.int32)
+    check(L.vslam_pgm_info(str(path).encode(), dims.ctypes.data, dims.ctypes.data + 4, dims.ctypes.data + 8))
+    gray = np.zeros((int(dims[1]), int(dims[0])), dtype=np.uint8)
+    check(L.vslam_pgm_read(str(path).encode(), gray.ctypes.data, gray.size, dims.ctypes.data, dims.ctypes.data + 4))
+    return gray
+
+
+def write_pgm(path, gray):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    check(_lib.lib().vslam_pgm_write(str(path).encode(), gray.ctypes.data, gray.shape[1], gray.shape[0], gray.shape[1]))
+
+
 def corner_params(block_size=7, border=None, max_features=10000, harris_k=0.04,
                   harris_thresh=1e-4, shi_thresh=1e-3):
     p = CornerParams()

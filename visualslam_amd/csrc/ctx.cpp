@@ -3,6 +3,7 @@
 #include <mutex>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <sstream>
@@ -378,6 +379,83 @@ vslam_status vslam_camera_from_xml(const char *path, vslam_camera *cam)
     for (int i = 0; i < 12; ++i)
         if (!std::isfinite(cam->d[i])) return VSLAM_ERR_IO;
     return VSLAM_OK;
+}
+
+// ---- binary PGM (P5) ----
+namespace {
+// Next header token of a PGM: skips white space and '#' comments (to the end of the line).  False at end of file
+// or when the token is not a decimal number of at most 9 digits.
+bool pgm_token(std::FILE *f, long *out)
+{
+    int c = std::fgetc(f);
+    for (;;) {
+        while (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f') c = std::fgetc(f);
+        if (c != '#') break;
+        while (c != '\n' && c != '\r' && c != EOF) c = std::fgetc(f);
+    }
+    if (c < '0' || c > '9') return false;
+    long v = 0;
+    int digits = 0;
+    while (c >= '0' && c <= '9') {
+        if (++digits > 9) return false;
+        v = v * 10 + (c - '0');
+        c = std::fgetc(f);
+    }
+    if (c != EOF) std::ungetc(c, f);
+    *out = v;
+    return true;
+}
+// Reads the header; on success the stream stands on the first sample.
+vslam_status pgm_header(std::FILE *f, int32_t *w, int32_t *h, int32_t *maxval)
+{
+    if (std::fgetc(f) != 'P' || std::fgetc(f) != '5') return VSLAM_ERR_IO;
+    long W, H, M;
+    if (!pgm_token(f, &W) || !pgm_token(f, &H) || !pgm_token(f, &M)) return VSLAM_ERR_IO;
+    const int c = std::fgetc(f);                           // exactly one white-space byte ends the header
+    if (!(c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f')) return VSLAM_ERR_IO;
+    if (W < 1 || H < 1 || W > 65536 || H > 65536 || M < 1 || M > 65535) return VSLAM_ERR_IO;
+    *w = (int32_t)W; *h = (int32_t)H; *maxval = (int32_t)M;
+    return VSLAM_OK;
+}
+}  // namespace
+
+vslam_status vslam_pgm_info(const char *path, int32_t *w, int32_t *h, int32_t *maxval)
+{
+    if (!path || !w || !h) return VSLAM_ERR_ARG;
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return VSLAM_ERR_IO;
+    int32_t m = 0;
+    const vslam_status st = pgm_header(f, w, h, &m);
+    std::fclose(f);
+    if (st == VSLAM_OK && maxval) *maxval = m;
+    return st;
+}
+
+vslam_status vslam_pgm_read(const char *path, uint8_t *gray, size_t cap, int32_t *w, int32_t *h)
+{
+    if (!path || !gray || !w || !h) return VSLAM_ERR_ARG;
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return VSLAM_ERR_IO;
+    int32_t m = 0;
+    vslam_status st = pgm_header(f, w, h, &m);
+    if (st == VSLAM_OK && m > 255) st = VSLAM_ERR_UNSUPPORTED;          // two bytes per sample
+    const size_t need = st == VSLAM_OK ? (size_t)*w * (size_t)*h : 0;
+    if (st == VSLAM_OK && need > cap) st = VSLAM_ERR_CAPACITY;
+    if (st == VSLAM_OK && std::fread(gray, 1, need, f) != need) st = VSLAM_ERR_IO;      // truncated file
+    std::fclose(f);
+    return st;
+}
+
+vslam_status vslam_pgm_write(const char *path, const uint8_t *gray, int w, int h, int stride)
+{
+    if (!path || !gray) return VSLAM_ERR_ARG;
+    if (w < 1 || h < 1 || w > 65536 || h > 65536 || stride < w) return VSLAM_ERR_SHAPE;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return VSLAM_ERR_IO;
+    bool ok = std::fprintf(f, "P5\n%d %d\n255\n", w, h) > 0;
+    for (int r = 0; ok && r < h; ++r) ok = std::fwrite(gray + (size_t)r * stride, 1, (size_t)w, f) == (size_t)w;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? VSLAM_OK : VSLAM_ERR_IO;
 }
 
 }  // extern "C"
