@@ -80,13 +80,49 @@ def cpu_baseline(x, y, vis, budget_s=12.0):
         orc.point_loglik_analytic(x[reps % x.shape[0]], y[reps % x.shape[0]], vis[reps % x.shape[0]], cam, SIGMA)
         reps += 1
     analytic = reps * L_LANDMARKS / (time.perf_counter() - t0)
+    cores = usable_cores()
+    allc = all_core_cpu_rate("loglik_analytic", 4.0, cores)
     return {
         "value": L_LANDMARKS / sec_per_hessian, "unit": "landmark updates/s", "cores": 1, "kind": "port",
         "sample": "oracle autodiff-faithful path: %d whole cost evaluations (value+gradient+Hessian, %d dual2nd "
                   "likelihood passes each) of the same C3 instances, %.1f s" % (inst, full_passes, dt),
         "seconds_per_cost_evaluation": sec_per_hessian,
         "analytic_port_updates_per_s": analytic,
+        "analytic_port_all_cores": None if allc is None else {
+            "value": allc["value"], "unit": "landmark updates/s", "cores": allc["cores"], "kind": "port",
+            "sample": "%d worker processes, each %d closed-form cost evaluations of its own 150-landmark instances in %.0f s"
+                      % (allc["cores"], allc["units"] // L_LANDMARKS // allc["cores"], allc["seconds_each"])},
+        "reference_faithful_all_cores_estimate": L_LANDMARKS / sec_per_hessian * cores,
+        "reference_faithful_all_cores_note": "the autodiff-faithful rate above times %d cores (independent instances share nothing); not run" % cores,
     }
+
+
+def usable_cores(cap=16):
+    """Host cores this process may use, at most `cap` (a one-GPU box gives one process a share of 16)."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    return max(1, min(cap, c))
+
+
+def all_core_cpu_rate(kind, seconds, cores):
+    """Units per second of the CPU oracle with one worker process per core, each on its own units (bench_cpu_worker.py);
+    the workers are child processes that never touch the GPU."""
+    import subprocess
+    worker = os.path.join(ROOT, "bench_cpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, kind, str(seconds), str(i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(cores)]
+    rate, units = 0.0, 0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 4 + 180)
+        line = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not line:
+            return None
+        r = json.loads(line[-1])
+        rate += r["units"] / r["seconds"]
+        units += r["units"]
+    return {"value": rate, "cores": cores, "units": units, "seconds_each": seconds}
 
 
 def host_info():
@@ -181,8 +217,20 @@ def main():
         ev[i][1].record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(step_ms))
     elapsed = sharding.max_over_ranks(elapsed, device=dev)
+    # median and inter-quartile range over at least 30 steps: the K timed steps plus, when K < 30, further steps
+    # taken after the timed region (they do not enter `value`)
+    extra = max(0, 30 - args.steps)
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
+    for a, b in ev2:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    step_ms += [a.elapsed_time(b) for a, b in ev2]
+    q1, med, q3 = (float(v) for v in np.percentile(step_ms, [25, 50, 75]))
     # results to rank 0 (outside the timed region): the only exchange a sharded batch needs
     all_vals = sharding.gather_to_root(val)
     gathered_ok = None if all_vals is None else bool(all(torch.isfinite(v).all().item() for v in all_vals) and len(all_vals) == world)
@@ -259,14 +307,32 @@ def main():
         units = B * L * args.steps * world
         alg = loglik_algorithmic_bytes(n, L) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None                        # not measured in this run: replayed from the committed counter passes
+        # HBM bytes per launch: not measured in this run (counters need rocprofv3 around the process) but replayed from
+        # the committed counter passes -- and only when this run's assemble kernel lasts what it lasted under those
+        # passes (within 5 %), i.e. when the profile belongs to the kernels that ran here
+        traffic, traffic_source = None, "no committed counter pass for this batch size"
         tfile = os.path.join(ROOT, "profiles", "traffic_point_loglik.json")
         if os.path.exists(tfile) and B == 512:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            ref_ms = tj.get("assemble_kernel_avg_ms")
+            if ref_ms is None:
+                traffic_source = "profiles/traffic_point_loglik.json carries no kernel duration to check this run against: not replayed"
+            elif abs(assemble_ms - ref_ms) <= 0.05 * ref_ms:
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("replayed from profiles/traffic_point_loglik.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "tools/run_loglik.py 512 150, FETCH doubled per the gfx950 note); checked in this run: loglik_assemble_kernel "
+                                  "%.4f ms here against %.4f ms in the profiled run (within 5 %%)" % (assemble_ms, ref_ms))
+            else:
+                traffic_source = ("NOT replayed: loglik_assemble_kernel lasts %.4f ms here against %.4f ms in the run "
+                                  "profiles/traffic_point_loglik.json was taken from" % (assemble_ms, ref_ms))
         out = {
             "metric": "landmark Jacobian updates/s", "value": units / elapsed, "unit": "landmark updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "step_stats": {"samples": len(step_ms), "median_ms": med, "q1_ms": q1, "q3_ms": q3, "iqr_ms": q3 - q1,
+                           "median_frac_of_hbm_roof": loglik_algorithmic_bytes(n, L) * B / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "HIP-event time of each step on the kernels' stream; the K timed steps%s" % (
+                               " plus %d steps after the timed region" % extra if extra else "")},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x%d: %d independent point-landmark updates per GPU per step, L=150 landmarks, "
                                    "n=462 states, log-lik + gradient + exact Hessian (BASELINE configs[2] batched as configs[4])"
@@ -275,8 +341,7 @@ def main():
                        "parallelism": "replicated instances, no collective"},
             "roofline": {"bound": "hbm", "kernel": "loglik_terms_kernel + loglik_assemble_kernel (one point_loglik call)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "replayed from profiles/traffic_point_loglik.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                           "tools/run_loglik.py 512 150, FETCH doubled per the gfx950 note); not re-measured in this run",
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
                          "kernels_apart": {"loglik_terms_kernel_ms": terms_ms, "loglik_assemble_kernel_ms": assemble_ms,
                                            "assemble_alone_frac": alg / (assemble_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -192,4 +192,10 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
             reps += 1
         res["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "%d synthetic 1080p frames, both detectors, oracle scalar C" % reps}
+        from bench import all_core_cpu_rate, usable_cores
+        allc = all_core_cpu_rate("corner", 4.0, usable_cores())
+        if allc is not None:
+            res["cpu_baseline_all_cores"] = {"value": allc["value"], "unit": "frames/s", "cores": allc["cores"], "kind": "port",
+                                             "sample": "%d worker processes, frame-level parallelism, %d synthetic 1080p frames in %.0f s each, both detectors"
+                                                       % (allc["cores"], allc["units"], allc["seconds_each"])}
     return res

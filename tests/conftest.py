@@ -37,16 +37,38 @@ def gcam():
     return api.camera_from_xml(syn.CAMERA_XML)
 
 
-@pytest.fixture(scope="session")
-def ctx():
-    """The library context shared by the GPU tests.  It runs on torch's current stream, so that tensors the tests
-    build with torch (fills, copies) are ordered before the library's kernels without a device-wide synchronisation;
-    tests that want a stream of the library's own create their context themselves."""
+_CONTEXTS = {}
+
+
+def _context(kind):
     import torch
     from visualslam_amd import api
-    c = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    yield c
-    c.close()
+    if kind not in _CONTEXTS:
+        _CONTEXTS[kind] = api.Context(0, stream=torch.cuda.current_stream().cuda_stream) if kind == "borrowed" else api.Context(0)
+    return _CONTEXTS[kind]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _close_contexts():
+    yield
+    for c in _CONTEXTS.values():
+        c.close()
+    _CONTEXTS.clear()
+
+
+@pytest.fixture
+def ctx(request):
+    """The library context shared by the GPU tests.  "borrowed" (the default) runs on torch's current stream, so that
+    tensors the tests build with torch (fills, copies) are ordered before the library's kernels without a device-wide
+    synchronisation.  "owned" is what Context(device) gives a caller: a non-blocking stream of the library's own;
+    modules that set BOTH_CONTEXTS = True run every test that takes `ctx` under both (a test that hands torch tensors
+    to an owned-stream context synchronises the device first)."""
+    return _context(getattr(request, "param", "borrowed"))
+
+
+def pytest_generate_tests(metafunc):
+    if "ctx" in metafunc.fixturenames and getattr(metafunc.module, "BOTH_CONTEXTS", False):
+        metafunc.parametrize("ctx", ["borrowed", "owned"], indirect=True)
 
 
 def rel_err(a, b, floor=None):

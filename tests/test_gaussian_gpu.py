@@ -8,6 +8,7 @@ import pytest
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
+BOTH_CONTEXTS = True      # every test that takes `ctx` runs on torch's stream and on a stream of the library's own
 TOL = 1e-9
 
 
@@ -89,6 +90,7 @@ def test_affine_bundle_bank_vs_oracle(ctx, gcam, ocam, layout):
     dmu = torch.full((B, m), float("nan"), dtype=torch.float64, device=dev)
     dSy = torch.full((B, m, m), float("nan"), dtype=torch.float64, device=dev)
     dc = torch.full((B, L), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()          # the inputs were made on torch's stream; the context may run on one of its own
     api.affine_bundle_batch_dev(ctx, gcam, dx, dS, dmu, dSy, dc, layout)
     ctx.synchronize()
     torch.cuda.synchronize()

@@ -10,6 +10,7 @@ import pytest
 from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
+BOTH_CONTEXTS = True      # every test that takes `ctx` runs on torch's stream and on a stream of the library's own
 
 
 def _gemm(ctx, A, B, transA=False, transB=False, amode=0, b_upper=False, alpha=1.0, beta=0.0, Cin=None, ksplit=1):
@@ -194,6 +195,54 @@ def test_two_contexts_solve_large_triangular_systems_at_once(ctx):
         j["ctx"].close()
 
 
+def test_small_chained_solves_beside_a_full_size_factorisation(ctx):
+    """A 6012 x 6012 factorisation (94 workgroups that wait for one another, 47 launches) from one context while two more
+    contexts on threads of their own run short chained solves (462 unknowns: 6 workgroups that wait for one another) --
+    launches small enough to run without taking the GPU's turn when their context is alone on the device.  With several
+    contexts on the device they do take it, so no launch can be left waiting for members that found no compute unit."""
+    import threading
+    import scipy.linalg as sla
+    import torch
+    from visualslam_amd import _lib, api
+    L = _lib.lib()
+    fn = L.vslam_debug_trsv_reps
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n, m = 6012, 462
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((n, n))
+    stream = torch.cuda.Stream()
+    qctx = api.Context(0, stream=stream.cuda_stream)
+    t = torch.tensor(np.ascontiguousarray(A.T), device="cuda:0")
+    torch.cuda.synchronize()
+    jobs = []
+    for k in range(2):
+        U = np.triu(rng.standard_normal((m, m))) / np.sqrt(m) + np.diag(1.0 + rng.random(m))
+        jobs.append({"U": U, "S": np.ascontiguousarray(U.T), "b": rng.standard_normal(m), "z": np.zeros(m), "ctx": api.Context(0), "rc": None, "trans": k})
+    def solve(j):
+        j["rc"] = fn(j["ctx"].ptr, j["S"].ctypes.data, m, j["trans"], j["b"].ctypes.data, j["z"].ctypes.data, 400)
+    qrc = {}
+    def factor():
+        try:
+            api.qr_upper_batch_dev(qctx, t, n, n, n, 1, n * n)
+            qctx.synchronize()
+            qrc["ok"] = True
+        except Exception as exc:           # surfaced below
+            qrc["ok"] = repr(exc)
+    threads = [threading.Thread(target=factor)] + [threading.Thread(target=solve, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert qrc.get("ok") is True, qrc
+    assert rel_err(t.cpu().numpy().T, np.linalg.qr(A, mode="r")) <= 1e-11
+    for j in jobs:
+        assert j["rc"] == 0, L.vslam_last_error(j["ctx"].ptr)
+        assert rel_err(j["z"], sla.solve_triangular(j["U"], j["b"], trans=j["trans"], lower=False)) <= 1e-11
+        j["ctx"].close()
+    qctx.close()
+
+
 def test_qr_tall_batched_many_workgroups(ctx):
     import torch
     from visualslam_amd import api
@@ -349,6 +398,27 @@ def test_triangular_vector_solve(ctx, n, trans):
     assert rel_err(z, z0) <= 1e-11
     res = (U.T @ z if trans else U @ z) - b
     assert np.abs(res).max() <= 1e-11 * max(1.0, np.abs(z).max()) * np.sqrt(n)
+
+
+@pytest.mark.parametrize("n", [462, 1000])
+@pytest.mark.parametrize("trans", [False, True])
+def test_triangular_vector_solve_returns_nans_for_a_nan_right_hand_side(ctx, n, trans):
+    """The chained solve marks an unpublished value with a NaN of all-ones bits.  A right-hand side that carries this
+    very NaN must still give a finished call whose dependent entries are NaN (as the one-launch-per-block path returns
+    them), not a reader polling to its bound and a device error."""
+    rng = np.random.default_rng(n)
+    U = np.triu(rng.standard_normal((n, n))) / np.sqrt(n) + np.diag(1.0 + rng.random(n))
+    b = rng.standard_normal(n)
+    k = n // 2
+    b[k] = np.frombuffer(np.array([-1], dtype=np.int64).tobytes(), dtype=np.float64)[0]
+    z = _trsv(ctx, np.ascontiguousarray(U.T), trans, b)                    # asserts status 0
+    dep = np.arange(n) >= k if trans else np.arange(n) <= k                # entries the NaN can reach
+    assert np.isnan(z[k]) and np.isnan(z[dep]).all()
+    assert np.isfinite(z[~dep]).all()
+    clean = b.copy()
+    clean[k] = 0.0
+    z0 = _trsv(ctx, np.ascontiguousarray(U.T), trans, clean)
+    assert np.array_equal(z[~dep], z0[~dep])
 
 
 def test_triangular_vector_solve_many_calls_in_a_row(ctx):

@@ -21,6 +21,7 @@ struct vslam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool counted = false;        // entered in the per-device count of live contexts
     void *ws = nullptr;          // device workspace of the entry points, grown on demand
     size_t ws_bytes = 0;
     void *scratch = nullptr;     // kernel-internal scratch (partial results), separate so that an
@@ -58,7 +59,9 @@ inline vslam_status fail(vslam_ctx *ctx, vslam_status s, const char *fmt, ...)
         va_start(ap, fmt);
         vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
         va_end(ap);
-        ctx->failed = true;      // device-to-host copies the failed call staged must not reach its host pointers later
+        // device-to-host copies the failed call staged must not reach its host pointers later; a call that staged none
+        // (an argument error, a diagnostic query) leaves the context as it was
+        if (!ctx->pending.empty()) ctx->failed = true;
     }
     return s;
 }
@@ -121,6 +124,15 @@ struct CamK {
     double cos_half_fov, wmax, hmax;
 };
 vslam_status resolve_camera(vslam_ctx *ctx, const vslam_camera *cam, CamK *out);
+
+// Most workgroups of ONE launch whose members wait for one another (blocked QR, chained triangular solve): such a launch
+// needs all its members resident at once, one per compute unit (each takes most of a unit's LDS).  Derived from the
+// compute-unit count the device reports when a context is created on it (16 units are left for launches that do not take
+// the GPU's turn below): 240 on a whole MI355X, less on a partitioned or masked one; the smallest over all devices this
+// process has contexts on.  Callers that would exceed it take their multi-launch paths instead.
+int resident_workgroup_cap();
+// Number of live contexts on the device: with more than one, launches of different contexts can overlap on the GPU.
+int contexts_on_device(int device);
 
 // Launches whose workgroups wait for one another (the blocked QR's exchange, the chained triangular solve with helper
 // workgroups) are queued one after the other on each GPU, whatever context or stream they come from: while the guard

@@ -160,8 +160,36 @@ vslam_status side_stream_init(vslam_ctx *ctx)
 }
 
 namespace {
-struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; };
+struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; int contexts = 0; };
 DeviceTurn g_turn[64];
+std::mutex g_cap_mutex;
+int g_resident_cap = 240;
+}
+
+int resident_workgroup_cap()
+{
+    std::lock_guard<std::mutex> lock(g_cap_mutex);
+    return g_resident_cap;
+}
+
+int contexts_on_device(int device)
+{
+    if (device < 0 || device >= 64) return 2;                   // no bookkeeping for such a device: assume company
+    std::lock_guard<std::mutex> lock(g_turn[device].m);
+    return g_turn[device].contexts;
+}
+
+static void note_context(int device, int compute_units, int delta)
+{
+    if (compute_units > 0) {
+        std::lock_guard<std::mutex> lock(g_cap_mutex);
+        const int cap = compute_units > 32 ? compute_units - 16 : (compute_units > 1 ? compute_units / 2 : 1);
+        if (cap < g_resident_cap) g_resident_cap = cap;
+    }
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lock(g_turn[device].m);
+        g_turn[device].contexts += delta;
+    }
 }
 
 DeviceTurnGuard::DeviceTurnGuard(vslam_ctx *ctx) : ctx_(ctx), st_(VSLAM_OK), held_(false)
@@ -266,6 +294,8 @@ static vslam_status ctx_make(int device, void *stream, bool borrow, vslam_ctx **
     }
     vslam_ctx *c = new vslam_ctx();
     c->device = device;
+    c->counted = true;
+    vslam::note_context(device, prop.multiProcessorCount, +1);
     if (borrow) {
         c->stream = static_cast<hipStream_t>(stream);
         c->own_stream = false;
@@ -300,7 +330,8 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
 {
     if (!ctx) return VSLAM_ERR_ARG;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->counted) vslam::note_context(ctx->device, 0, -1);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->potf_dinv) (void)hipFree(ctx->potf_dinv);

@@ -385,9 +385,11 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     // One workgroup per matrix either way: the chain form of tri.hip where its blocks fit LDS (VSLAM_BANK_TRSV_OLD=1 keeps
     // the older kernel for A/B runs), bk_trsv_kernel otherwise.
     const bool chain_trsv = trsv_upper_bank_fits(n) && !getenv("VSLAM_BANK_TRSV_OLD");
-    auto trsv = [&](const double *M, bool trans, const double *rhs, double *out, double scale, const int *mask, int count) {
-        if (chain_trsv) (void)trsv_upper_bank_dev(ctx, M, n, n, nn, trans, rhs, out, scale, mask, count);
-        else hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
+    auto trsv = [&](const double *M, bool trans, const double *rhs, double *out, double scale, const int *mask, int count) -> vslam_status {
+        if (chain_trsv) return trsv_upper_bank_dev(ctx, M, n, n, nn, trans, rhs, out, scale, mask, count);
+        hipLaunchKernelGGL(bk_trsv_kernel, dim3(count), dim3(BK_T), trsv_lds, s, M, n, nn, n, trans ? 1 : 0, rhs, out, scale, mask);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        return VSLAM_OK;
     };
     // A mask over the filters, or over all slots; the device array always holds Bt mask words and, behind them, the
     // slots of the mask as a list (nlisted of them): the factorisations and their solves launch over the list, so a
@@ -430,7 +432,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         PotrfFrom from{w.Hcur, nn, w.lam, 0.0};
         VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, nn, rows, w.info, selp, /*zero_lower=*/false, w.t, (size_t)n, by_list, &from));
         if (by_list) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, false, w.t, w.p, -1.0, selp, rows, true));
-        else trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt);
+        else VSLAM_TRY(trsv(w.U, false, w.t, w.p, -1.0, w.active, Bt));
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         return VSLAM_OK;
     };
@@ -439,8 +441,8 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     auto eval = [&](std::vector<double> &V) -> vslam_status {
         const int *a = w.active;
         hipLaunchKernelGGL(bk_sub_kernel, dim3(1, B), dim3(256), 0, s, w.x, mu, w.tmp, (size_t)n, a);
-        trsv(S, true, w.tmp, w.tmp, 1.0, a, B);                           // z = S^-T (x - mu)
-        trsv(S, false, w.tmp, w.gp, 1.0, a, B);                           // S^-1 z (negated below)
+        VSLAM_TRY(trsv(S, true, w.tmp, w.tmp, 1.0, a, B));                // z = S^-T (x - mu)
+        VSLAM_TRY(trsv(S, false, w.tmp, w.gp, 1.0, a, B));                // S^-1 z (negated below)
         hipLaunchKernelGGL(bk_log_gaussian_value_kernel, dim3(B), dim3(BK_T), 0, s, w.tmp, S, nn, n, w.vp, w.gp, a);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (!prior_ready) {                                               // the prior Hessian does not depend on x
@@ -543,7 +545,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         for (int kk = 0; kk < 20 && any(m); ++kk) {
             VSLAM_TRY(send_mask(m));
             if (chain_trsv && nlisted < Bt) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, true, w.p, w.q, 1.0, listv, nlisted, true));
-            else trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt);
+            else VSLAM_TRY(trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt));
             VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
             drop_failed(m);
             std::vector<int> stop(Bt, 0);

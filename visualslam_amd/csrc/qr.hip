@@ -487,7 +487,9 @@ __global__ __launch_bounds__(256) void qr_block_solve_kernel(const double *Ypart
 static int coop_rows_per(int rows, int batch)
 {
     if (rows < 128 || batch > 8) return 0;
-    const int gmax = (240 / batch) < CP_GMAX ? (240 / batch) : CP_GMAX;
+    const int cap = resident_workgroup_cap();
+    if (cap / batch < 2) return 0;
+    const int gmax = (cap / batch) < CP_GMAX ? (cap / batch) : CP_GMAX;
     int rp = rows >= 2048 ? 128 : 64;                  // measured: fewer, fatter workgroups lose to the LDS pass
     if ((rows + rp - 1) / rp > gmax) rp = (((rows + gmax - 1) / gmax) + 7) & ~7;
     return rp > CP_RMAX ? 0 : rp;
@@ -949,8 +951,8 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
 vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
 {
     QrBlockPlan pl;
-    const bool waits = rows >= 1 && cols >= 1 && batch >= 1 && qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl) && pl.G > 1 &&
-                       true;
+    const bool waits = rows >= 1 && cols >= 1 && batch >= 1 &&
+                       ((qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl) && pl.G > 1) || coop_rows_per(rows, batch) > 0);
     if (!waits) return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
     DeviceTurnGuard turn(ctx);                        // queued behind the previous such factorisation or solve on this GPU
     if (turn.status() != VSLAM_OK) return turn.status();

@@ -966,7 +966,9 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
 bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
 {
     if (rows < 1 || batch < 1) return false;
-    const int gcap = batch <= 8 ? 240 / batch : 240;       // workgroups per matrix that are certainly resident together
+    const int cap = resident_workgroup_cap();              // 240 on a whole MI355X
+    const int gcap = batch <= 8 ? cap / batch : cap;       // workgroups per matrix that are certainly resident together
+    if (gcap < 1) return false;
     int bw = bw_want < 32 ? 32 : (bw_want > QB_BW_MAX ? QB_BW_MAX : (bw_want & ~31));
     if (batch > 8) bw = 32;                                // banks: one panel per launch, as few workgroups per matrix as LDS allows
     for (; bw >= 32; bw -= 32) {
@@ -991,7 +993,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
         }
         if (lds > QB_LDS_MAX) continue;
         p->bw = bw; p->rows_per = rp; p->ldr = rp + 2; p->G = (rows + rp - 1) / rp;
-        if (p->G > 240) continue;
+        if (p->G > gcap) continue;
         p->cmax = bw > 32 ? 32 * bw : 1024;                    // W of one panel of reflectors against every resident column
         p->lds_bytes = lds < ((size_t)96 << 10) ? ((size_t)96 << 10) : lds;     // one workgroup per compute unit
         p->xbuf_doubles = 2 * ((size_t)(p->G + 1) * p->cmax + 1024);      // two words per value: contributions, sums, top rows
@@ -1006,19 +1008,20 @@ vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPl
 {
     if (bwc > pl.bw || nfac > bwc || nfac > mp || nfac < 1) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d columns (%d to factor) in a block of %d", bwc, nfac, pl.bw);
     const int G = (mp + pl.rows_per - 1) / pl.rows_per;
-    if (G > pl.G || G > 240) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d workgroups per matrix exceed the plan (%d)", G, pl.G);
+    const int cap = resident_workgroup_cap();
+    if (G > pl.G || G > cap) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d workgroups per matrix exceed the plan (%d)", G, pl.G);
     if (roff < 0 || roff % 32 != 0 || (roff > 0 && (!Vprev || !Tprev || batch != 1 || nfac > mp - roff)))
         return fail(ctx, VSLAM_ERR_SHAPE, "qr block: inconsistent previous-block arguments");
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&qr_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     // The workgroups of a matrix wait for one another, so all workgroups of a launch must be resident together: a bank
-    // is cut into launches of at most 240 workgroups (they follow one another on the stream).
+    // is cut into launches of at most resident_workgroup_cap() workgroups (they follow one another on the stream).
     int per_launch = batch;
     if (G > 1) {
         int per_cu = 0, cus = 0;
         VSLAM_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, qr_block_kernel, QB_T, pl.lds_bytes));
         VSLAM_HIP_TRY(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
         int room = per_cu * cus;
-        if (room > 240) room = 240;
+        if (room > cap) room = cap;
         if (per_cu < 1 || G > room)
             return fail(ctx, VSLAM_ERR_CAPACITY, "qr block: %d workgroups that wait for one another, but only %d x %d fit on the device", G, per_cu, cus);
         per_launch = room / G;

@@ -20,7 +20,7 @@ struct QrBlockPlan {
     size_t lds_bytes;
     size_t xbuf_doubles;    // exchange buffer per matrix
 };
-// False when no arrangement fits (batch > 8, or more rows than 240 workgroups can hold).
+// False when no arrangement fits (batch > 8, or more rows than resident_workgroup_cap() workgroups can hold).
 bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p);
 
 // Factors the first `nfac` columns of the block whose first element is A (rows mp), keeping `bwc` >= nfac columns

@@ -220,8 +220,7 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *S, int n, 
 // arithmetic), which the TC_LAG-1 links in between cover.
 // Published values are their own ready marks: `sol` (solutions, then sums: a stretch of the context's ring that no
 // earlier launch has used since the ring was last filled) holds a NaN of all-ones bits and a reader polls until the
-// pattern is gone.  (A value that is itself this NaN -- only a right-hand side holding the same pattern produces
-// one -- ends in the bounded wait below.)  All workgroups are resident together (at most TC_MAX of 256 compute
+// pattern is gone (a value that is itself this NaN is published as the canonical quiet NaN, chain_publishable).  All workgroups are resident together (at most TC_MAX of 256 compute
 // units, one workgroup each; a launch of more than 16 takes the GPU's turn, see trsv_upper_dev); a wait that
 // exceeds its bound raises *err and lets every wave run to the end.
 // rhs and z may be the same vector (an entry is read one link before it is written); z = scale * solution.
@@ -273,6 +272,14 @@ struct ChainGeo {
         return ps >= 0 && pd < nblk && row < n && col < n;
     }
 };
+
+// A value as it is published: the one bit pattern that means "not ready" (a NaN of all-ones bits, which a right-hand
+// side or a matrix holding that very NaN would propagate) is replaced by the canonical quiet NaN, so a reader sees a
+// NaN arrive -- and the solve returns NaNs as the one-launch-per-block path does -- instead of polling to its bound.
+__device__ __forceinline__ double chain_publishable(double v)
+{
+    return __double_as_longlong(v) == -1ll ? __longlong_as_double(0x7ff8000000000000ll) : v;
+}
 
 // Polls one published value; false once the launch has been declared dead.
 __device__ __forceinline__ double chain_wait(const double *p, int *err, bool &dead)
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             if (trans) {
                 const double tot = chain_reduce8(acc, lane);
                 if ((lane & 7) == 0)
-                    __hip_atomic_store(&sums[(size_t)pos * TBK + w + 8 * jl], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sums[(size_t)pos * TBK + w + 8 * jl], chain_publishable(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 part[w * TBK + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
             }
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
                 double h = 0.0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) h += part[q * TBK + tid];
-                __hip_atomic_store(&sums[(size_t)pos * TBK + tid], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sums[(size_t)pos * TBK + tid], chain_publishable(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(TC_T) void trsv_chain_kernel(const double *S, int n
             const int c = g.at(i, lane);
             const double x = (c >= 0) ? v * rinvs[(i & 3) * TBK + lane] : 0.0;
             xring[xslot(i) * TBK + lane] = x;
-            if (!BANK) __hip_atomic_store(&sol[(size_t)i * TBK + lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!BANK) __hip_atomic_store(&sol[(size_t)i * TBK + lane], chain_publishable(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c >= 0) z[c] = scale * x;
             lds_barrier();
         }
@@ -621,7 +628,9 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
 {
     hipStream_t s = ctx->stream;
     const int nblk = (n + TBK - 1) / TBK;
-    if (nblk > 1 && nblk <= TC_MAX) {
+    const int helpers_wanted = nblk > TC_LAG ? nblk - TC_LAG : 0;
+    // the chain's workgroups wait for one another: only when all of them can be resident together (else one launch per block, below)
+    if (nblk > 1 && nblk <= TC_MAX && 1 + helpers_wanted <= resident_workgroup_cap()) {
         const size_t lds = (size_t)TC_LDS_DOUBLES * 8, need = (size_t)2 * nblk * TBK;
         VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&trsv_chain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -632,9 +641,12 @@ vslam_status trsv_upper_dev(vslam_ctx *ctx, const double *S, int n, int ldS, boo
         double *sol = ctx->chain_sol + ctx->chain_used;
         ctx->chain_used += need;
         const int helpers = nblk > TC_LAG ? nblk - TC_LAG : 0;
-        // More workgroups than the blocked QR's launcher leaves free (it keeps to 240 of 256 compute units): take the GPU's
-        // turn, so that this launch and such a factorisation from another context never wait for members that found no room.
-        if (1 + helpers > 16) {
+        // Take the GPU's turn, so that this launch and a blocked factorisation or another chain from another context never
+        // wait for members that found no room: always when the launch is larger than what the factorisation's launcher
+        // leaves free (16 compute units), and for any multi-workgroup chain once a second context lives on the device --
+        // two small chains beside a full-size factorisation add up to more than the device holds.  (A single context
+        // queues all such launches on its one stream; a second PROCESS on the GPU is outside what this can order.)
+        if (1 + helpers > 16 || (helpers > 0 && contexts_on_device(ctx->device) > 1)) {
             DeviceTurnGuard turn(ctx);
             if (turn.status() != VSLAM_OK) return turn.status();
             if (trans) hipLaunchKernelGGL((trsv_chain_kernel<true, false>), dim3(1 + helpers), dim3(TC_T), lds, s, S, n, ldS, b, scale, z, sol, ctx->flags, (size_t)0, (const int *)nullptr, 0);
