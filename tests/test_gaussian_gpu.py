@@ -204,25 +204,64 @@ def test_measurement_update_iekf_vs_oracle(ctx, gcam, ocam, L, seed, solver):
     assert rel_err(np.linalg.inv(Sp.T @ Sp), H1) <= 1e-6
 
 
-def test_measurement_update_iekf_indefinite_falls_back(ctx, gcam, ocam):
-    """A start far from the optimum with a loose prior makes the exact likelihood Hessian indefinite:
-    the device route hands over to the eigenvalue route and the result still matches the oracle."""
-    from oracle import pyoracle as orc
-    from visualslam_amd import api, synthetic as syn
+def _indefinite_start(seed=2):
+    """A start far from the optimum with a loose prior: the exact likelihood Hessian makes the joint Hessian indefinite
+    at the first iterates."""
+    from visualslam_amd import synthetic as syn
     sc = syn.Scene(6, 3)
     S = np.diag(np.concatenate([np.full(6, 0.1), np.full(6, 0.5), np.full(18, 5.0)]))
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(seed)
     mu = sc.x + np.concatenate([np.zeros(6), 0.05 * rng.standard_normal(6), 0.8 * rng.standard_normal(18)])
-    ctx.set_trs_solver(api.TRS_CHOLESKY)
-    try:
-        ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
-    finally:
-        ctx.set_trs_solver(api.TRS_CHOLESKY)        # the library default
+    return sc, mu, S
+
+
+def test_measurement_update_iekf_indefinite_stays_on_the_device(ctx, gcam, ocam):
+    """An indefinite Hessian (src/fmin.cpp:59-69 starts the multiplier above -l1 in the eigenbasis): the device route
+    meets it as a failed Cholesky factorisation, shifts by the failed pivot until the factorisation succeeds and carries
+    on with the same secular equation; the update stays on the device and matches the oracle's eigenvalue route."""
+    from oracle import pyoracle as orc
+    from visualslam_amd import api
+    sc, mu, S = _indefinite_start()
+    H0 = api.cost_joint_density(ctx, gcam, mu, mu, S, sc.y, sc.visible, sc.sigma)[2]
+    assert np.linalg.eigvalsh(H0)[0] < 0.0                          # the case is what it claims to be
+    ret, mup, Sp, iters, evals = api.measurement_update_iekf(ctx, gcam, mu, S, sc.y, sc.visible, sc.sigma)
     ret0, mup0, Sp0, iters0, evals0 = orc.measurement_update_iekf(mu, S, sc.y, sc.visible, ocam, sc.sigma)
-    assert ctx.last_trs_route() == api.TRS_EIG
-    assert (ret, iters, evals) == (ret0, iters0, evals0)
+    assert ctx.last_trs_route() == api.TRS_CHOLESKY
+    assert ret == ret0 and abs(iters - iters0) <= 2 and abs(evals - evals0) <= 2
     assert np.max(np.abs(mup - mup0) / np.maximum(np.abs(mup0), 1e-3)) <= 1e-6
     assert rel_err(Sp.T @ Sp, Sp0.T @ Sp0) <= 1e-6
+    assert not np.tril(Sp, -1).any()
+
+
+def test_bank_with_indefinite_filters_finishes_them(ctx, gcam, ocam):
+    """The same in a bank: filters with indefinite Hessians beside well-behaved ones all come back finished
+    (status 0) and match the oracle filter by filter."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    cases = [_indefinite_start(2), _indefinite_start(5), _indefinite_start(9)]
+    sc0 = syn.Scene(6, 3)
+    cases.append((sc0, sc0.x.copy(), np.diag(sc0.diag)))            # a positive definite filter among them
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(np.stack([c[1] for c in cases]), device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(c[2].T) for c in cases]), device=dev)
+    y = torch.tensor(np.stack([c[0].y for c in cases]), device=dev)
+    vis = torch.tensor(np.stack([c[0].visible for c in cases]).astype(np.uint8), device=dev)
+    mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+    torch.cuda.synchronize()
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, 7.0, mup, Sp)
+    torch.cuda.synchronize()
+    assert not status.any()
+    indefinite = 0
+    for b, (sc, m_, S_) in enumerate(cases):
+        H0 = api.cost_joint_density(ctx, gcam, m_, m_, S_, sc.y, sc.visible, sc.sigma)[2]
+        indefinite += np.linalg.eigvalsh(H0)[0] < 0.0
+        ret0, mup0, Sp0, it0, _ = orc.measurement_update_iekf(m_, S_, sc.y, sc.visible, ocam, sc.sigma)
+        m1, S1 = mup[b].cpu().numpy(), Sp[b].cpu().numpy().T
+        assert code[b] == ret0 and abs(int(iters[b]) - it0) <= 2
+        assert np.max(np.abs(m1 - mup0) / np.maximum(np.abs(mup0), 1e-3)) <= 1e-6
+        assert rel_err(S1.T @ S1, Sp0.T @ Sp0) <= 1e-6
+    assert indefinite >= 2
 
 
 def test_measurement_update_iekf_2000_landmarks(ctx, gcam):

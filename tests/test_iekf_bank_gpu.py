@@ -35,14 +35,11 @@ def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
     Sp = torch.empty_like(S)
     code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, scs[0].sigma, mup, Sp)
     torch.cuda.synchronize()
-    assert status.sum() < B
+    assert not status.any()                    # every filter is finished on the device, indefinite Hessians included
     ctx.set_trs_solver(api.TRS_CHOLESKY)
     try:
         for b, sc in enumerate(scs):
             c0, m0, S0, it0, _ = api.measurement_update_iekf(ctx, gcam, mus[b], sc.S, sc.y, sc.visible, sc.sigma)
-            if status[b]:                      # not positive definite somewhere: the single-filter entry falls back too
-                assert ctx.last_trs_route() == api.TRS_EIG
-                continue
             assert ctx.last_trs_route() == api.TRS_CHOLESKY
             m1 = mup[b].cpu().numpy()
             S1 = Sp[b].cpu().numpy().T

@@ -17,6 +17,7 @@
 // with M M^T = H (a Cholesky factorisation of the index-reversed H).  It equals the reference's S up
 // to the signs of its rows, which there depend on the eigensolver's choice of eigenvector signs.
 #include "potf.hpp"
+#include "trs_search.hpp"
 
 #include <chrono>
 
@@ -360,8 +361,8 @@ vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *inf
     return potrf_upper_batch_dev(ctx, A, n, lda, 0, 1, info, nullptr);
 }
 
-// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.  With `info`,
-// out[3] carries *info instead (the factorisation's verdict travels to the host with the dot products).
+// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.  out[4] carries
+// *info (the factorisation's verdict travels to the host with the dot products).
 struct DotArgs { const double *a[4]; const double *b[4]; };
 __global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *out, const int *info)
 {
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *ou
     if (tid < 4) {
         double sum = 0.0;
         for (int w = 0; w < 16; ++w) sum += red[tid][w];
-        out[tid] = (tid == 3 && info) ? (double)*info : sum;
+        out[tid] = sum;
+        if (tid == 0) out[4] = info ? (double)*info : 0.0;
     }
 }
 
@@ -464,10 +466,10 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     hipStream_t s = ctx->stream;
     NewtonDevice w;
     newton_carve(ws, n, &w);
-    const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
+    const double eps = std::numeric_limits<double>::epsilon();
     const int nb = (n + 255) / 256;
     int evals = 0, factorisations = 0;
-    double hd[4];
+    double hd[5];
     int hinfo = 0;
     *status_out = 0;
     // Wall-clock split of the call for the bench's breakdown; every phase below ends at a stream synchronisation
@@ -479,15 +481,23 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     double ms_cost = 0.0, ms_trs = 0.0;
     auto phase_to = [&](double &acc) { acc += ms_since(t_phase); t_phase = clk::now(); };
 
-    auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
+    auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2,
+                    const double *a3 = nullptr, const double *b3 = nullptr) -> vslam_status {
         DotArgs d;
-        d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = nullptr; d.b[3] = nullptr;
+        d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = a3; d.b[3] = b3;
         hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(d2h(ctx, hd, w.dots, 4 * 8));
+        VSLAM_TRY(d2h(ctx, hd, w.dots, 5 * 8));
         VSLAM_TRY(stream_sync(ctx));
-        hinfo = (int)hd[3];
+        hinfo = (int)hd[4];
         return VSLAM_OK;
+    };
+    // moments of the multiplier search (trs_search.hpp) at the current factor: |p|^2, |U^-T p|^2, |U^-1 U^-T p|^2, |U^-T U^-1 U^-T p|^2
+    auto moments = [&]() -> vslam_status {
+        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.p, w.q));
+        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.q, w.t));
+        VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.t, w.spare));
+        return dots(w.p, w.p, w.q, w.q, w.t, w.t, w.spare, w.spare);
     };
     // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&](double lam) -> vslam_status {
@@ -522,24 +532,30 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     VSLAM_TRY(accept());
     int ret = 1, it;
     for (it = 0; it < 50; ++it) {
-        // ---- trust-region subproblem, src/fmin.cpp:40-131 with l1 > 0 ----
-        double lam = 0.0;
-        VSLAM_TRY(factor_and_step(lam));
-        VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
-        if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
-        double pn = std::sqrt(hd[0]);
-        if (pn > Delta) {
-            for (int kk = 0; kk < 20; ++kk) {
-                VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.p, w.q));
-                VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
-                const double ppn = std::sqrt(hd[0]), dpp = hd[1];
-                const double ff = 1 / Delta - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);   // d|p|/dlam = -p'(H+lam I)^-1 p / |p|
-                const double lam_new = std::max(0.0, lam - ff / gg);
-                if (lam_new == lam) break;      // same multiplier, same factor and p: the remaining steps would change nothing
-                lam = lam_new;
-                VSLAM_TRY(factor_and_step(lam));
-                if (std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta)) break;
+        // ---- trust-region subproblem, src/fmin.cpp:40-131, by the multiplier search of trs_search.hpp ----
+        TrsSlot ts;
+        ts.Delta = Delta;
+        for (bool first = true;; first = false) {
+            VSLAM_TRY(factor_and_step(ts.lam));
+            if (first) VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
+            else VSLAM_TRY(moments());
+            if (hinfo != 0) {
+                // H + lam I is not positive definite: its first non-positive pivot sits on the factor's diagonal
+                double pivot = 0.0;
+                VSLAM_TRY(d2h(ctx, &pivot, w.U + (size_t)(hinfo - 1) * n + (hinfo - 1), 8));
+                VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, 16 * sizeof(int), s));
+                VSLAM_TRY(stream_sync(ctx));
+                if (trs_after_failure(ts, pivot) == TRS_GIVE_UP) { *status_out = 1; return VSLAM_OK; }
+                continue;
             }
+            if (first) {
+                if (trs_interior(ts, hd[0])) break;                 // the Newton step lies inside the region
+                VSLAM_TRY(moments());
+            }
+            const TrsNext next = trs_after_solve(ts, hd[0], hd[1], hd[2], hd[3]);
+            if (next == TRS_GIVE_UP) { *status_out = 1; return VSLAM_OK; }
+            if (next == TRS_DONE) break;
+            if (next == TRS_REFACTOR_LAST) { VSLAM_TRY(factor_and_step(ts.lam)); break; }      // its verdict arrives with the dot products below
         }
         // ---- src/fmin.hpp:54-105 ----
         if (n >= MV_SLABS) {                           // Hp = Hcur * p; the factor in w.U is spent, its memory takes the slab sums
@@ -555,8 +571,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         hipLaunchKernelGGL(axpby_kernel, dim3(nb), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n);
         VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hp, w.p, w.p));
         if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
-        const double pg = hd[0], pHp = hd[1];
-        pn = std::sqrt(hd[2]);
+        const double pg = hd[0], pHp = hd[1], pn = std::sqrt(hd[2]);
         phase_to(ms_trs);
         if (std::fabs(-pg) < 2 * eps) { ret = 0; break; }
         VSLAM_TRY(eval_at(w.xn, &fn));

@@ -12,6 +12,7 @@
 // with vslam_measurement_update_iekf.
 #include "landmark_math.hpp"
 #include "linalg.hpp"
+#include "trs_search.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -124,26 +125,27 @@ __global__ __launch_bounds__(BK_T) void bk_trsv_kernel(const double *S, int ldS,
     for (int i = tid; i < n; i += BK_T) out[(size_t)b * n + i] = scale * z[i];
 }
 
-// out[b][q] = a_q[b] . b_q[b], q < 3 (null pairs give 0); one workgroup per active instance.
-struct BkDotArgs { const double *a[3]; const double *b[3]; };
+// out[b][q] = a_q[b] . b_q[b], q < 4 (null pairs give 0); one workgroup per active instance.  out[b][4] = info[b].
+constexpr int BK_DOTS = 8;                       // doubles per slot in the result
+struct BkDotArgs { const double *a[4]; const double *b[4]; };
 __global__ __launch_bounds__(BK_T) void bk_dots_kernel(BkDotArgs d, int n, double *out, const int *active, const int *info)
 {
-    __shared__ double red[3][BK_T / 64];
+    __shared__ double red[4][BK_T / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (info && tid == 0) out[(size_t)b * 4 + 3] = (double)info[b];      // every slot's factorisation flag travels with the dot products
+    if (info && tid == 0) out[(size_t)b * BK_DOTS + 4] = (double)info[b];      // every slot's factorisation flag travels with the dot products
     if (active && !active[b]) return;
-    double acc[3] = {0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = tid; i < n; i += BK_T)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 4; ++q)
             if (d.a[q]) acc[q] += d.a[q][(size_t)b * n + i] * d.b[q][(size_t)b * n + i];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 4; ++q) {
         const double v = wave_sum(acc[q]);
         if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
     __syncthreads();
-    if (tid < 3) out[(size_t)b * 4 + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
+    if (tid < 4) out[(size_t)b * BK_DOTS + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
 }
 
 // out[b] = a * x[b] + c * y[b] over vectors of length n (y may be null), active instances only
@@ -304,7 +306,7 @@ struct BankWs {
     double *Hp, *Hl, *W;                                                    // [B][n*n]
     double *U, *Hcur;                                                       // [Bt][n*n]
     double *x, *tmp, *gp, *gl, *g, *xcur, *gcur, *p, *t, *q, *xn, *Hpv;     // [Bt][n]
-    double *vp, *vl, *V, *dots, *lam;                                       // [Bt] ([Bt][4] for dots)
+    double *vp, *vl, *V, *dots, *lam;                                       // [Bt] ([Bt][BK_DOTS] for dots)
     int *info, *active, *map;                                               // [Bt]
     void *tws;
 };
@@ -313,7 +315,7 @@ size_t bank_ws_bytes(int n, int B, int Bt)
 {
     const size_t nn = (size_t)n * n;
     return 3 * Arena::pad((size_t)B * nn * 8) + 2 * Arena::pad((size_t)Bt * nn * 8) + 12 * Arena::pad((size_t)Bt * n * 8) +
-           9 * Arena::pad((size_t)Bt * 4 * 8) + trtri_batch_ws_bytes(n, B);
+           9 * Arena::pad((size_t)Bt * 4 * 8) + Arena::pad((size_t)Bt * BK_DOTS * 8) + trtri_batch_ws_bytes(n, B);
 }
 
 void bank_carve(void *ws, int n, int B, int Bt, BankWs *w)
@@ -325,7 +327,7 @@ void bank_carve(void *ws, int n, int B, int Bt, BankWs *w)
     double **v[12] = {&w->x, &w->tmp, &w->gp, &w->gl, &w->g, &w->xcur, &w->gcur, &w->p, &w->t, &w->q, &w->xn, &w->Hpv};
     for (double **q : v) *q = ar.take<double>((size_t)Bt * n);
     w->vp = ar.take<double>(4 * Bt); w->vl = ar.take<double>(4 * Bt); w->V = ar.take<double>(4 * Bt);
-    w->dots = ar.take<double>(4 * Bt); w->lam = ar.take<double>(4 * Bt);
+    w->dots = ar.take<double>((size_t)BK_DOTS * Bt); ar.take<double>(4 * Bt); w->lam = ar.take<double>(4 * Bt);
     w->info = reinterpret_cast<int *>(ar.take<double>(4 * Bt));
     ar.take<double>(4 * Bt);
     w->active = reinterpret_cast<int *>(w->lam + Bt);      // mask and list sit behind the multipliers: one upload carries all three
@@ -372,11 +374,11 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     bank_carve(ctx->ws, n, B, Bt, &w);
     const size_t trsv_lds = (size_t)(((n + 1) & ~1) + 64 * 65 + 64) * 8;
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&bk_trsv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trsv_lds));
-    const double eps = std::numeric_limits<double>::epsilon(), sqrteps = std::sqrt(eps);
+    const double eps = std::numeric_limits<double>::epsilon();
 
     // per slot (filters 0 .. B-1, then the slots solved ahead)
     std::vector<int> trs(Bt, 0), m(Bt, 0), hinfo(Bt, 0), map(Bt, -1);
-    std::vector<double> Delta(Bt, 1.0), lam(Bt, 0.0), hd((size_t)4 * Bt, 0.0);
+    std::vector<double> Delta(Bt, 1.0), lam(Bt, 0.0), hd((size_t)BK_DOTS * Bt, 0.0);
     // per filter
     std::vector<int> act(B, 1), acc(B, 0), ret(B, 1), its(B, MAX_ITERATIONS), stat(B, 0), done(B, 0), itb(B, 0), rej(B, 0), cur(B, 0);
     std::vector<double> f(B, 0.0), fn(B, 0.0);
@@ -410,14 +412,15 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     };
     auto any = [&](const std::vector<int> &h) { return std::any_of(h.begin(), h.end(), [](int v) { return v != 0; }); };
     // results of bk_dots_kernel and the factorisation flags of all slots
-    auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2) -> vslam_status {
+    auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2,
+                    const double *a3 = nullptr, const double *b3 = nullptr) -> vslam_status {
         BkDotArgs d;
-        d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2;
+        d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = a3; d.b[3] = b3;
         hipLaunchKernelGGL(bk_dots_kernel, dim3(Bt), dim3(BK_T), 0, s, d, n, w.dots, w.active, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)4 * Bt * 8));
+        VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)BK_DOTS * Bt * 8));
         VSLAM_TRY(stream_sync(ctx));
-        for (int sl = 0; sl < Bt; ++sl) hinfo[sl] = (int)hd[(size_t)4 * sl + 3];
+        for (int sl = 0; sl < Bt; ++sl) hinfo[sl] = (int)hd[(size_t)BK_DOTS * sl + 4];
         return VSLAM_OK;
     };
     // for the slots of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
@@ -475,10 +478,12 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         hipLaunchKernelGGL(bk_gather_kernel, dim3(grid_for(count), slots), dim3(256), 0, s, dst, src, count, w.map);
     };
     auto send_map = [&]() -> vslam_status { return h2d(ctx, w.map, map.data(), (size_t)Bt * sizeof(int)); };
-    // a non-positive pivot: a filter leaves the bank; a slot solved ahead just drops out with everything behind it
-    auto drop_failed = [&](std::vector<int> &mask) {
+    // a slot whose subproblem cannot be finished here (the hard case of an indefinite Hessian, a Hessian that is not
+    // finite): a filter leaves the bank (status 1); a slot solved ahead just drops out with everything behind it
+    auto drop_failed = [&](std::vector<int> &mask, int only = -1) {
         for (int sl = 0; sl < Bt; ++sl) {
-            if (hinfo[sl] == 0 || !trs[sl]) continue;
+            if (only >= 0 ? sl != only : hinfo[sl] == 0) continue;
+            if (!trs[sl]) continue;
             trs[sl] = 0; mask[sl] = 0; m[sl] = 0;
             if (sl < B) { stat[sl] = 1; done[sl] = 1; act[sl] = 0; ahead[sl].clear(); }
             else
@@ -532,39 +537,67 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 VSLAM_HIP_TRY(ctx, hipGetLastError());
             }
         }
-        // ---- trust-region subproblems, src/fmin.cpp:40-131 with l1 > 0 ----
+        // ---- trust-region subproblems, src/fmin.cpp:40-131: every slot runs the multiplier search of trs_search.hpp ----
         std::fill(lam.begin(), lam.end(), 0.0);
+        std::vector<TrsSlot> ts(Bt);
+        std::vector<int> Q(Bt, 0), R(Bt, 0), last(Bt, 0), failed(Bt, 0), scratch(Bt, 0);
+        std::vector<double> piv(Bt, 0.0);
+        bool info_dirty = false;
+        for (int sl = 0; sl < Bt; ++sl) ts[sl].Delta = Delta[sl];
         VSLAM_TRY(send_mask(trs, true));
         VSLAM_TRY(factor_and_step());
         VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
-        {
-            std::vector<int> scratch(Bt, 0);
-            drop_failed(scratch);
+        for (int sl = 0; sl < Bt; ++sl) {
+            if (!trs[sl]) continue;
+            if (hinfo[sl]) failed[sl] = 1;                                               // H itself is not positive definite
+            else if (!trs_interior(ts[sl], hd[(size_t)BK_DOTS * sl])) Q[sl] = 1;          // the Newton step leaves the region
         }
-        for (int sl = 0; sl < Bt; ++sl) m[sl] = trs[sl] && std::sqrt(hd[(size_t)4 * sl]) > Delta[sl];
-        for (int kk = 0; kk < 20 && any(m); ++kk) {
-            VSLAM_TRY(send_mask(m));
-            if (chain_trsv && nlisted < Bt) VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, true, w.p, w.q, 1.0, listv, nlisted, true));
-            else VSLAM_TRY(trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt));
-            VSLAM_TRY(dots(w.p, w.p, w.q, w.q, nullptr, nullptr));
-            drop_failed(m);
-            std::vector<int> stop(Bt, 0);
-            for (int sl = 0; sl < Bt; ++sl)
-                if (m[sl]) {
-                    const double ppn = std::sqrt(hd[(size_t)4 * sl]), dpp = hd[(size_t)4 * sl + 1];
-                    const double ff = 1 / Delta[sl] - 1 / ppn, gg = -dpp / (ppn * ppn * ppn);
-                    const double lam_new = std::max(0.0, lam[sl] - ff / gg);
-                    // see trs_multiplier_settled() in linalg.hpp
-                    stop[sl] = std::fabs(ff) < sqrteps || trs_multiplier_settled(ff, Delta[sl]);
-                    if (lam_new == lam[sl]) { stop[sl] = 1; m[sl] = 0; }    // same multiplier: nothing to refactor
-                    lam[sl] = lam_new;
+        for (int kk = 0; kk < 80; ++kk) {
+            if (any(failed)) {
+                // the first non-positive pivot of each failed factorisation sits on the factor's diagonal
+                for (int sl = 0; sl < Bt; ++sl)
+                    if (failed[sl]) VSLAM_TRY(d2h(ctx, &piv[sl], w.U + (size_t)sl * nn + (size_t)(hinfo[sl] - 1) * n + (hinfo[sl] - 1), 8));
+                VSLAM_TRY(stream_sync(ctx));
+                for (int sl = 0; sl < Bt; ++sl) {
+                    if (!failed[sl]) continue;
+                    failed[sl] = 0;
+                    if (trs_after_failure(ts[sl], piv[sl]) == TRS_GIVE_UP) { drop_failed(scratch, sl); continue; }
+                    lam[sl] = ts[sl].lam; R[sl] = 1; last[sl] = 0;
                 }
-            if (!any(m)) break;
-            ++trace_steps;
-            VSLAM_TRY(send_mask(m, true));
-            VSLAM_TRY(factor_and_step());
-            for (int sl = 0; sl < Bt; ++sl)
-                if (stop[sl]) m[sl] = 0;
+                info_dirty = true;
+            }
+            if (any(R)) {
+                ++trace_steps;
+                if (info_dirty) { VSLAM_HIP_TRY(ctx, hipMemsetAsync(w.info, 0, (size_t)Bt * sizeof(int), s)); info_dirty = false; }
+                VSLAM_TRY(send_mask(R, true));
+                VSLAM_TRY(factor_and_step());
+                for (int sl = 0; sl < Bt; ++sl)
+                    if (R[sl]) { R[sl] = 0; if (!last[sl]) Q[sl] = 1; }                     // a last factorisation's verdict arrives with the dot products further down
+            }
+            if (!any(Q)) break;
+            // moments of the search at every fresh factor: |p|^2, |U^-T p|^2, |U^-1 U^-T p|^2, |U^-T U^-1 U^-T p|^2
+            VSLAM_TRY(send_mask(Q));
+            if (chain_trsv && nlisted < Bt) {
+                VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, true, w.p, w.q, 1.0, listv, nlisted, true));
+                VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, false, w.q, w.t, 1.0, listv, nlisted, true));
+                VSLAM_TRY(trsv_upper_bank_dev(ctx, w.U, n, n, nn, true, w.t, w.Hpv, 1.0, listv, nlisted, true));
+            } else {
+                VSLAM_TRY(trsv(w.U, true, w.p, w.q, 1.0, w.active, Bt));
+                VSLAM_TRY(trsv(w.U, false, w.q, w.t, 1.0, w.active, Bt));
+                VSLAM_TRY(trsv(w.U, true, w.t, w.Hpv, 1.0, w.active, Bt));
+            }
+            VSLAM_TRY(dots(w.p, w.p, w.q, w.q, w.t, w.t, w.Hpv, w.Hpv));
+            for (int sl = 0; sl < Bt; ++sl) {
+                if (!Q[sl]) continue;
+                Q[sl] = 0;
+                if (!trs[sl]) continue;
+                if (hinfo[sl]) { failed[sl] = 1; continue; }
+                const double *h4 = &hd[(size_t)BK_DOTS * sl];
+                const TrsNext next = trs_after_solve(ts[sl], h4[0], h4[1], h4[2], h4[3]);
+                if (next == TRS_GIVE_UP) { drop_failed(scratch, sl); continue; }
+                if (next == TRS_DONE) continue;
+                lam[sl] = ts[sl].lam; R[sl] = 1; last[sl] = next == TRS_REFACTOR_LAST;
+            }
         }
         // ---- src/fmin.hpp:54-105: predicted decrease and the trial point of every slot ----
         VSLAM_TRY(send_mask(trs));
@@ -574,10 +607,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         }
         hipLaunchKernelGGL(bk_axpby_kernel, dim3(nb, Bt), dim3(256), 0, s, 1.0, w.xcur, 1.0, w.p, w.xn, n, w.active);
         VSLAM_TRY(dots(w.p, w.gcur, w.p, w.Hpv, w.p, w.p));
-        {
-            std::vector<int> scratch(Bt, 0);
-            drop_failed(scratch);
-        }
+        drop_failed(scratch);                                 // a last factorisation that failed after all: the filter is handed back
         // ---- the filters' iterations: first on their own subproblem, then, rejected step after rejected step, on
         //      those solved ahead ----
         std::vector<int> pend(act);
@@ -585,7 +615,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         while (any(pend)) {
             ++trace_levels;
             for (int b = 0; b < B; ++b)
-                if (pend[b] && std::fabs(-hd[(size_t)4 * cur[b]]) < 2 * eps) {                       // src/fmin.hpp:61-67
+                if (pend[b] && std::fabs(-hd[(size_t)BK_DOTS * cur[b]]) < 2 * eps) {                       // src/fmin.hpp:61-67
                     ret[b] = 0; its[b] = itb[b]; done[b] = 1; act[b] = 0; pend[b] = 0; ahead[b].clear();
                 }
             if (!any(pend)) break;
@@ -601,7 +631,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 acc[b] = 0;
                 if (!pend[b]) continue;
                 const int sl = cur[b];
-                const double pg = hd[(size_t)4 * sl], pHp = hd[(size_t)4 * sl + 1], pnb = std::sqrt(hd[(size_t)4 * sl + 2]);
+                const double pg = hd[(size_t)BK_DOTS * sl], pHp = hd[(size_t)BK_DOTS * sl + 1], pnb = std::sqrt(hd[(size_t)BK_DOTS * sl + 2]);
                 const double dm = -pg - 0.5 * pHp, rho = (f[b] - fn[b]) / dm;
                 double Dn = Delta[sl];
                 if (rho < 0.1) Dn = 0.25 * pnb;

@@ -26,8 +26,8 @@ __device__ __forceinline__ double potf_rsqrt(double d)
 // finished rows above them (left-looking; per finished row one own-column read and eight broadcast reads feed
 // eight multiply-adds held in registers), then are factored among themselves with lane broadcasts.  Entries below
 // the diagonal are neither meaningful on entry nor on return.  invd[k] = 1 / U_kk.  A non-positive pivot in the
-// first jb rows stores its 1-based global column (j0 + row + 1) in *info (first one wins); the arithmetic carries
-// on with NaNs.
+// first jb rows stores its 1-based global column (j0 + row + 1) in *info (first one wins) and stays, unscaled, on the
+// diagonal of U (the value the trust-region search shifts by, trs_search.hpp); the arithmetic carries on with NaNs.
 __device__ __attribute__((noinline)) void potf2_lds(double *U, double *invd, int jb, int j0, int *info)
 {
     const int lane = threadIdx.x & 63;
@@ -50,7 +50,8 @@ __device__ __attribute__((noinline)) void potf2_lds(double *U, double *invd, int
             const double dkk = readlane_f64(acc[r], row);
             if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
             const double inv = rsqrt(dkk);                       // one reciprocal square root per row instead of a square root and a division
-            const double u = (lane == row) ? dkk * inv : acc[r] * inv;     // row `row` of U (meaningful for lanes >= row)
+            // row `row` of U (meaningful for lanes >= row); a non-positive pivot is left on the diagonal as it is, for the caller to read
+            const double u = (lane == row) ? (dkk > 0.0 ? dkk * inv : dkk) : acc[r] * inv;
             U[row * PLD + lane] = u;
             if (lane == row) invd[row] = inv;
 #pragma unroll
@@ -89,7 +90,7 @@ __device__ __forceinline__ void potf2_lds4(double *U, double *invd, int jb, int 
                 const double dkk = readlane_f64(acc[r], row);
                 if (!(dkk > 0.0) && row < jb && !bad) { bad = true; if (lane == row) atomicCAS(info, 0, j0 + row + 1); }
                 const double inv = rsqrt(dkk);
-                const double u = (lane == row) ? dkk * inv : acc[r] * inv;
+                const double u = (lane == row) ? (dkk > 0.0 ? dkk * inv : dkk) : acc[r] * inv;     // a non-positive pivot stays on the diagonal as it is
                 U[row * PLD + lane] = u;
                 if (lane == row) invd[row] = inv;
 #pragma unroll

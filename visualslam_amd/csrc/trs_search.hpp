@@ -1,0 +1,124 @@
+// Host-side search for the multiplier of one trust-region subproblem
+//     minimise g'p + p'Hp/2  subject to |p| <= Delta            (src/fmin.cpp:40-131)
+// when all that is available per trial multiplier lam is a Cholesky factorisation H + lam I = U'U on the device (or
+// its failure) and a few triangular solves.  The reference works in the eigenbasis of H: it starts at lam = 0 (or at
+// 1.01 |l1| when the smallest eigenvalue l1 is negative), takes Newton steps on 1/Delta - 1/|p(lam)| with the lower
+// clamp max(0, -l1), stops once |1/Delta - 1/|p|| < sqrt(eps) and evaluates p at the multiplier one step further.
+// The subproblem has one solution on the boundary (outside the "hard case"), so any safeguarded iteration that ends
+// with the same test and the same final step arrives at the reference's p to rounding; what differs is the number
+// of factorisations on the way.  Two things keep that number small:
+//   * with p = -(H + lam I)^-1 g the moments m_k = p'(H + lam I)^-(k-2) p, k = 2..5, are the squared norms of
+//     p, U^-T p, U^-1 U^-T p, U^-T U^-1 U^-T p (one triangular solve each).  They are the first four moments of the
+//     measure that writes |p(lam + d)|^2 as an integral of 1 / (1 + d t)^2, so a two-node Gauss rule reproduces
+//     |p(lam + d)|^2 far beyond the tangent the Newton step uses; the next multiplier is the root of that model
+//     (three to four factorisations per subproblem where the Newton iteration takes six to eight);
+//   * an indefinite H shows up as a failed factorisation.  The first non-positive pivot d of H + lam I bounds the
+//     shift that repairs the leading block (every later Schur complement grows by at least the shift), so the next
+//     trial is lam - d (plus a margin); trials that fail raise `lo`, trials that succeed with |p| < Delta lower `hi`,
+//     and model steps that leave (lo, hi) are replaced by its midpoint (More & Sorensen's safeguards).  The hard case
+//     (no root above -l1) ends with the bracket collapsing: the caller falls back to the eigenvalue route.
+#pragma once
+
+#include <cmath>
+#include <limits>
+
+namespace vslam {
+
+struct TrsSlot {
+    double Delta = 1.0;
+    double lam = 0.0;          // multiplier of the factorisation last requested
+    double lo = 0.0;           // largest multiplier at which the factorisation failed (0: none failed; lam = 0 then counts as failing only if `indefinite`)
+    double hi = std::numeric_limits<double>::infinity();     // smallest multiplier that factored with |p| <= Delta
+    double left = -1.0;        // largest multiplier that factored with |p| > Delta (the root lies above it); -1: none yet
+    double bump = 0.0;         // extra shift after repeated failures
+    bool indefinite = false;   // some factorisation failed
+    int steps = 0, fails = 0;
+};
+
+enum TrsNext { TRS_DONE = 0, TRS_REFACTOR = 1, TRS_REFACTOR_LAST = 2, TRS_GIVE_UP = 3 };
+
+// Root d of the two-node Gauss model of |p(lam + d)|^2 = Delta^2; false when the moments do not give a proper rule.
+inline bool trs_model_step(double m2, double m3, double m4, double m5, double Delta, double *d_out)
+{
+    if (!(m2 > 0.0 && m3 > 0.0 && m4 > 0.0 && m5 > 0.0) || !std::isfinite(m2 + m3 + m4 + m5)) return false;
+    const double s = m3 / m2;                                  // scale of t = 1 / (eigenvalue + lam)
+    const double u2 = m4 / (m2 * s * s), u3 = m5 / (m2 * s * s * s);      // scaled moments u0 = u1 = 1
+    const double det = 1.0 - u2;                               // <= 0 (Cauchy-Schwarz); 0 for a one-point measure
+    if (!(det < -1e-10)) return false;
+    const double c1 = (u3 - u2) / det, c0 = (u2 * u2 - u3) / det;          // t^2 + c1 t + c0 orthogonal to 1 and t
+    const double disc = c1 * c1 - 4.0 * c0;
+    if (!(disc > 0.0)) return false;
+    const double rt = std::sqrt(disc), t1 = 0.5 * (-c1 - rt), t2 = 0.5 * (-c1 + rt);
+    if (!(t1 > 0.0 && t2 > t1)) return false;
+    const double w2 = (1.0 - t1) / (t2 - t1), w1 = 1.0 - w2;
+    if (!(w1 > 0.0 && w2 > 0.0)) return false;
+    const double target = Delta * Delta / m2;
+    auto f = [&](double x) { const double a = 1.0 + x * t1, b = 1.0 + x * t2; return w1 / (a * a) + w2 / (b * b); };
+    double xl, xh;                                             // f decreases from +inf at -1/t2 to 0
+    if (target < 1.0) { xl = 0.0; xh = 1.0; int guard = 0; while (f(xh) > target && ++guard < 2000) xh *= 4.0; if (guard >= 2000) return false; }
+    else { xl = -(1.0 - 1e-12) / t2; xh = 0.0; }
+    for (int it = 0; it < 200; ++it) {
+        const double xm = 0.5 * (xl + xh);
+        if (xm == xl || xm == xh) break;
+        if (f(xm) > target) xl = xm; else xh = xm;
+    }
+    *d_out = 0.5 * (xl + xh) / s;
+    return std::isfinite(*d_out);
+}
+
+// Stopping rule next to the reference's |ff| < sqrt(eps), ff = 1/Delta - 1/|p| (src/fmin.cpp:118-126): once the trust
+// region has shrunk (Delta << 1) that absolute test asks for more digits than ff has, and the reference then simply runs
+// its 20 Newton steps, which cost nothing in the eigenbasis; here each step is a factorisation.  When |p| matches Delta
+// to 1e-10 relative the step taken from that ff moves p by less than that: the search stops without it.
+inline bool trs_settled(double ff, double Delta) { return std::fabs(ff) * Delta < 1e-10; }
+
+// The factorisation at s.lam failed; `pivot` is its first non-positive pivot.
+inline TrsNext trs_after_failure(TrsSlot &s, double pivot)
+{
+    s.indefinite = true;
+    if (!(pivot <= 0.0) || ++s.fails > 40) return TRS_GIVE_UP;          // NaN pivot (the matrix itself is not finite), or no end in sight
+    if (s.lam > s.lo) s.lo = s.lam;
+    const double floor_ = 1e-10 * (1.0 + s.lam);
+    s.bump = s.bump > 0.0 ? 4.0 * s.bump : floor_;
+    double next = s.lam + std::fmax(-1.01 * pivot, s.bump);
+    const double top = std::isfinite(s.hi) ? s.hi : (s.left >= 0.0 ? s.left : std::numeric_limits<double>::infinity());
+    if (std::isfinite(top)) {
+        if (!(top - s.lo > 1e-13 * top)) return TRS_GIVE_UP;           // bracket collapsed: hard case
+        if (next >= top) next = 0.5 * (s.lo + top);
+    }
+    s.lam = next;
+    return TRS_REFACTOR;
+}
+
+// The factorisation at s.lam succeeded and gave |p|^2 = m2; interior = this was the plain Newton step (lam = 0, no
+// failure before): it is the solution when it lies inside the region.
+inline bool trs_interior(const TrsSlot &s, double m2) { return !s.indefinite && s.lam == 0.0 && std::sqrt(m2) <= s.Delta; }
+
+// ... and the three further moments: decides whether the search is over and where the next factorisation goes.
+inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, double m5)
+{
+    const double sqrteps = std::sqrt(std::numeric_limits<double>::epsilon());
+    const double pn = std::sqrt(m2), D = s.Delta;
+    if (!(pn > 0.0) || !std::isfinite(pn)) return TRS_GIVE_UP;
+    const double ff = 1.0 / D - 1.0 / pn;
+    if (trs_settled(ff, D)) return TRS_DONE;
+    const bool conv = std::fabs(ff) < sqrteps;
+    if (pn > D) { if (s.lam > s.left) s.left = s.lam; }
+    else if (s.lam < s.hi) s.hi = s.lam;
+    s.bump = 0.0;
+    double d = 0.0, next;
+    if (trs_model_step(m2, m3, m4, m5, D, &d)) next = s.lam + d;
+    else next = s.lam - ff / (-m3 / (pn * pn * pn));                    // the reference's Newton step (src/fmin.cpp:121-123)
+    // the root lies in (max(left, lo), hi)
+    const double lower = std::fmax(s.left >= 0.0 ? s.left : 0.0, s.lo);
+    const bool lower_open = s.left >= 0.0 || s.indefinite;              // the bound itself is not a candidate
+    if (std::isfinite(s.hi) && !(next < s.hi)) next = 0.5 * (lower + s.hi);
+    if (lower_open ? !(next > lower) : !(next >= lower)) next = std::isfinite(s.hi) ? 0.5 * (lower + s.hi) : (lower > 0.0 ? 2.0 * lower : 1.0);
+    if (std::isfinite(s.hi) && !(s.hi - lower > 1e-13 * s.hi) && !conv) return s.indefinite ? TRS_GIVE_UP : TRS_DONE;
+    if (next == s.lam) return TRS_DONE;
+    if (++s.steps > 24) return TRS_DONE;                                // the reference gives up after 20 steps and uses what it has
+    s.lam = next;
+    return conv ? TRS_REFACTOR_LAST : TRS_REFACTOR;
+}
+
+}  // namespace vslam
