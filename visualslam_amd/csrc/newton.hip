@@ -20,6 +20,8 @@
 #include "trs_search.hpp"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cmath>
 #include <limits>
@@ -531,11 +533,13 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     VSLAM_TRY(eval_at(c->x, &f));                                        // src/fmin.hpp:39
     VSLAM_TRY(accept());
     int ret = 1, it;
+    const bool trace = getenv("VSLAM_TRS_TRACE") != nullptr;       // diagnostic: the multipliers tried, per iteration
     for (it = 0; it < 50; ++it) {
         // ---- trust-region subproblem, src/fmin.cpp:40-131, by the multiplier search of trs_search.hpp ----
         TrsSlot ts;
         ts.Delta = Delta;
         for (bool first = true;; first = false) {
+            if (trace) std::fprintf(stderr, "  iteration %d: Delta %.6g, factorisation at multiplier %.10g\n", it, Delta, ts.lam);
             VSLAM_TRY(factor_and_step(ts.lam));
             if (first) VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
             else VSLAM_TRY(moments());
