@@ -150,7 +150,7 @@ vslam_status vslam_point_loglik_batch_dev(vslam_ctx *ctx, const vslam_camera *ca
 /* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc); it has no counterpart in the reference.  It calls no hipMalloc / hipFree: the
  * per-landmark records and per-block pose sums between its two kernels live in a static device array of the
- * library (about 10.7 MB per GPU, held until the process ends) whose address is looked up at context creation.
+ * library (about 13.5 MB per GPU, held until the process ends) whose address is looked up at context creation.
  * Limits: batch * L <= 81920 landmarks and batch * ceil(L / 256) <= 4096, else VSLAM_ERR_CAPACITY; when H is
  * given, ldH must equal n.  Results are those of vslam_point_loglik_batch_dev bit for bit (same kernels).
  * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (different streams or contexts)

@@ -659,13 +659,14 @@ __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
     __shared__ int st[FT_SH][FT_SW + 1];
     constexpr int FT_STAGE = 512;                      // staged candidates per tile; the rare tile with more appends the rest one by one
     __shared__ uint64_t stage[FT_STAGE];
-    __shared__ int lcnt, gbase;
+    __shared__ uint16_t queue[FT_SH * FT_SW];          // positions (lx | ly << 8) that passed both quick tests
+    __shared__ int lcnt, gbase, qn;
     const int tid = threadIdx.x;
     const int frame = blockIdx.x % a.frames, tile = blockIdx.x / a.frames;
     const int x0 = (tile % a.tiles_x) * FT_W, y0 = (tile / a.tiles_x) * FT_H;
     const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
     const int w = a.w, h = a.h;
-    if (tid == 0) lcnt = 0;
+    if (tid == 0) { lcnt = 0; qn = 0; }
     if (((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)a.stride) & 3) == 0) {
         // rows start on 4-byte boundaries and x0 - 4 is a multiple of 4: whole words, bytes past the image zeroed
         for (int idx = tid; idx < FT_IH * (FT_IW / 4); idx += FT_T) {
@@ -685,34 +686,48 @@ __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
         }
     }
     __syncthreads();
-    // strengths of the tile and its 1-pixel ring (FT_SW x FT_SH): 64 columns x FT_T / 64 rows per pass, then the two
-    // remaining columns
-    auto strength_at = [&](int lx, int ly) {
+    // Strengths of the tile and its 1-pixel ring (FT_SW x FT_SH), in two passes.  Pass 1 -- every position: an arc of 9
+    // of the 16 ring pixels contains one pixel of every opposite pair, so the vertical pair rejects most pixels and the
+    // horizontal one most others; the few that pass both are queued in LDS.  Pass 2 -- the queue, densely packed: the
+    // full segment test.  (Evaluated in place, a wavefront pays for the full test whenever ONE of its 64 pixels needs
+    // it, which on textured frames is most wavefronts: 137 instructions per pixel against 30 + 250 per queued pixel.)
+    auto quick_at = [&](int lx, int ly) {
         const int px = x0 - 1 + lx, py = y0 - 1 + ly;
-        int s = 0;
+        bool pass = false;
         if (px >= 3 && py >= 3 && px < w - 3 && py < h - 3) {
             const int cy = ly + 3, cx = lx + 3, v = img[cy][cx], t = a.threshold;
-            // an arc of 9 of the 16 ring pixels contains one pixel of every opposite pair: the vertical pair
-            // rejects most pixels (whole wavefronts in flat regions stop here), the horizontal one most others
             const int q0 = img[cy + 3][cx] - v, q8 = img[cy - 3][cx] - v;
             const bool up = max(q0, q8) > t, dn = min(q0, q8) < -t;
             if (up || dn) {
                 const int q4 = img[cy][cx + 3] - v, q12 = img[cy][cx - 3] - v;
-                if ((up && max(q4, q12) > t) || (dn && min(q4, q12) < -t)) {
-                    int d[16];
-                    d[0] = q0;                        d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
-                    d[4] = q4;                        d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
-                    d[8] = q8;                        d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
-                    d[12] = q12;                      d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
-                    s = fast9_strength(d);
-                    if (s <= t) s = 0;
-                }
+                pass = (up && max(q4, q12) > t) || (dn && min(q4, q12) < -t);
             }
         }
-        st[ly][lx] = s;
+        st[ly][lx] = 0;
+        // wave-aggregated append: one LDS atomic per wavefront
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&qn, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (pass) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(lx | (ly << 8));
+        }
     };
-    for (int ly = tid >> 6; ly < FT_SH; ly += FT_T / 64) strength_at(tid & 63, ly);
-    if (tid < 2 * FT_SH) strength_at(FT_W + (tid & 1), tid >> 1);
+    for (int ly = tid >> 6; ly < FT_SH; ly += FT_T / 64) quick_at(tid & 63, ly);
+    if (tid < 2 * FT_SH) quick_at(FT_W + (tid & 1), tid >> 1);        // the two remaining columns (the ballot counts the active lanes only)
+    __syncthreads();
+    for (int i = tid; i < qn; i += FT_T) {
+        const int lx = queue[i] & 255, ly = queue[i] >> 8;
+        const int cy = ly + 3, cx = lx + 3, v = img[cy][cx], t = a.threshold;
+        int d[16];
+        d[0] = img[cy + 3][cx] - v;       d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
+        d[4] = img[cy][cx + 3] - v;       d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
+        d[8] = img[cy - 3][cx] - v;       d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
+        d[12] = img[cy][cx - 3] - v;      d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
+        const int sv = fast9_strength(d);
+        if (sv > t) st[ly][lx] = sv;
+    }
     __syncthreads();
     for (int ly = tid >> 6; ly < FT_H; ly += FT_T / 64) {
         const int lx = tid & 63, px = x0 + lx, py = y0 + ly;
@@ -808,6 +823,54 @@ __global__ __launch_bounds__(256) void orb_harris_kernel(OrbHarrisArgs a)
     a.cand[((size_t)f * 2 + 1) * CAND_CAP + i] = make_key(resp, ft.x, ft.y);
 }
 
+// The same for the 7 x 7 block on an image whose rows start on 4-byte boundaries: the 9 x 9 patch of a corner arrives as
+// nine 12-byte loads (the aligned words that cover columns x-4 .. x+4) instead of ~400 scattered byte reads -- the
+// kernel above spends its time on cache-line transactions, 64 per load instruction of a wavefront -- and the gradients
+// come from shared differences: Ix = (1 2 1)^T applied to the horizontal central differences, Iy = (1 2 1) applied to
+// the vertical ones.  Integer sums: the same values whatever the order.
+__global__ __launch_bounds__(256) void orb_harris7_kernel(OrbHarrisArgs a)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int kept = a.kept[f];
+    if (i == 0) a.cand_count[(size_t)f * 2 + 1] = kept < 0 ? 0 : kept;
+    if (i >= kept) return;
+    vslam_feature ft;
+    unpack_key(a.cand[(size_t)f * 2 * CAND_CAP + i], &ft);
+    const uint8_t *gray = a.gray + (size_t)f * a.stride_frame;
+    const int xa = (ft.x - 4) & ~3, sh = (ft.x - 4) - xa;
+    int p[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(gray + (size_t)(ft.y - 4 + r) * a.stride + xa);
+        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+        const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh), b2 = w2 >> (8 * sh);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { p[r][c] = (b0 >> (8 * c)) & 255; p[r][4 + c] = (b1 >> (8 * c)) & 255; }
+        p[r][8] = b2 & 255;
+    }
+    int D[9][7], V[7][9];                                  // D[r][c] = p[r][c+2] - p[r][c],  V[r][c] = p[r+2][c] - p[r][c]
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) D[r][c] = p[r][c + 2] - p[r][c];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) V[r][c] = p[r + 2][c] - p[r][c];
+    int sa = 0, sb = 0, sc = 0;
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            const int Ix = D[r][c] + 2 * D[r + 1][c] + D[r + 2][c], Iy = V[r][c] + 2 * V[r][c + 1] + V[r][c + 2];
+            sa += Ix * Ix; sb += Iy * Iy; sc += Ix * Iy;
+        }
+    const float fa = (float)sa, fb = (float)sb, fc = (float)sc;
+    const float tr = __fadd_rn(fa, fb);
+    const float resp = __fmul_rn(__fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(a.k, tr), tr)), a.scale4);
+    a.cand[((size_t)f * 2 + 1) * CAND_CAP + i] = make_key(resp, ft.x, ft.y);
+}
+
 __global__ void orb_emit_kernel(const uint64_t *cand, const int32_t *kept, int cap, vslam_feature *out, int32_t *count)
 {
     const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -837,6 +900,53 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t *src
     const unsigned p10 = src[(size_t)y1 * sstride + x0], p11 = src[(size_t)y1 * sstride + x1];
     const unsigned v = p00 * (2048 - ax) * (2048 - ay) + p01 * ax * (2048 - ay) + p10 * (2048 - ax) * ay + p11 * ax * ay;
     dst[(size_t)y * dstride + x] = (uint8_t)((v + (1u << 21)) >> 22);
+}
+
+// The same resize, four adjacent output pixels per thread: one 64-bit division per thread for the first pixel's source
+// position and one for the row's, then the exact quotient and remainder are carried from pixel to pixel (the numerator
+// grows by 2 * sw * 1024 = qs * dw + rs per pixel), and the four bytes leave as one word when the destination's rows
+// start on 4-byte boundaries.  The kernel above spends its time on two 64-bit divisions per pixel.
+__global__ __launch_bounds__(256) void resize_bilinear4_kernel(const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw,
+                                                               int dh, int dstride, size_t dframe, int qs, int rs, int word_stores)
+{
+    const int x = 4 * (blockIdx.x * 256 + threadIdx.x), y = blockIdx.y;
+    if (x >= dw) return;
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    long long Y = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
+    Y = Y < 0 ? 0 : (Y > (long long)(sh - 1) * 2048 ? (long long)(sh - 1) * 2048 : Y);
+    const int y0 = (int)(Y >> 11), ay = (int)(Y & 2047), y1 = min(y0 + 1, sh - 1);
+    const uint8_t *r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
+    const long long N = (long long)(2 * x + 1) * sw * 1024;
+    long long q = N / dw;
+    int r = (int)(N - q * dw);
+    const long long xmax = (long long)(sw - 1) * 2048;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long X = q - 1024;
+        X = X < 0 ? 0 : (X > xmax ? xmax : X);
+        const int x0 = (int)(X >> 11), ax = (int)(X & 2047), x1 = min(x0 + 1, sw - 1);
+        const unsigned p00 = r0[x0], p01 = r0[x1], p10 = r1[x0], p11 = r1[x1];
+        const unsigned v = p00 * (2048 - ax) * (2048 - ay) + p01 * ax * (2048 - ay) + p10 * (2048 - ax) * ay + p11 * ax * ay;
+        o |= ((v + (1u << 21)) >> 22) << (8 * i);
+        q += qs; r += rs;
+        if (r >= dw) { r -= dw; ++q; }
+    }
+    uint8_t *d = dst + (size_t)y * dstride + x;
+    if (word_stores && x + 4 <= dw) *reinterpret_cast<uint32_t *>(d) = o;
+    else for (int i = 0; i < 4 && x + i < dw; ++i) d[i] = (uint8_t)(o >> (8 * i));
+}
+
+static vslam_status launch_resize(vslam_ctx *ctx, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
+                                  int dstride, size_t dframe, int frames)
+{
+    const long long step = 2ll * sw * 1024;                  // numerator step of the source position per output pixel
+    const int words = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dstride | (uintptr_t)dframe) & 3) == 0;
+    hipLaunchKernelGGL(resize_bilinear4_kernel, dim3((dw + 1023) / 1024, dh, frames), dim3(256), 0, ctx->stream, src, sw, sh, sstride, sframe, dst, dw, dh,
+                       dstride, dframe, (int)(step / dw), (int)(step % dw), words);
+    VSLAM_HIP_TRY(ctx, hipGetLastError());
+    return VSLAM_OK;
 }
 
 static size_t orb_ws_bytes(int frames) { return detect_ws_bytes(frames) + Arena::pad((size_t)frames * 2 * 4); }
@@ -872,7 +982,9 @@ static vslam_status launch_orb_level(vslam_ctx *ctx, const uint8_t *gray, int w,
         ha.scale4 = s4;
     }
     ha.cand = a.cand; ha.cand_count = a.cand_count; ha.kept = kept;
-    hipLaunchKernelGGL(orb_harris_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
+    const bool words = block == 7 && ((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)stride | (uintptr_t)stride_frame) & 3) == 0;
+    if (words) hipLaunchKernelGGL(orb_harris7_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
+    else hipLaunchKernelGGL(orb_harris_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
     hipLaunchKernelGGL(sort_chunk_kernel, dim3(1, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 2);
     hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 1, nfeatures, kept + frames);
     const int lim = cap < SORT_S ? cap : SORT_S;
@@ -1173,7 +1285,7 @@ extern "C" vslam_status vslam_resize_bilinear_dev(vslam_ctx *ctx, const uint8_t 
     if (sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw || dstride < dw || sw > 65535 || sh > 65535 || dw > 65535 || dh > 65535)
         return fail(ctx, VSLAM_ERR_SHAPE, "resize: %dx%d (stride %d) -> %dx%d (stride %d)", sw, sh, sstride, dw, dh, dstride);
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, ctx->stream, src, sw, sh, sstride, (size_t)0, dst, dw, dh, dstride, (size_t)0);
+    VSLAM_TRY(launch_resize(ctx, src, sw, sh, sstride, (size_t)0, dst, dw, dh, dstride, (size_t)0, 1));
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
@@ -1226,10 +1338,15 @@ static vslam_status orb_run(vslam_ctx *ctx, const uint8_t *gray, int w, int h, i
     for (int l = 0; l < nl; ++l) VSLAM_TRY(check_orb_level(ctx, lw[l], lh[l], lw[l], lf[l], p->fast_threshold, p->edge_threshold, p->harris_block));
     VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
     VSLAM_TRY(ensure_lds_attr(ctx));
+    // rows of the library's own level images and of the blurred copy start on 16-byte boundaries (the kernels then
+    // move whole words); the bytes between a row's end and the next row's start are never used
+    int lsd[VSLAM_ORB_MAX_LEVELS];
+    for (int l = 0; l < nl; ++l) lsd[l] = (lw[l] + 15) & ~15;
+    const int bsd = (w + 15) & ~15;
     size_t pyr = 0;
-    for (int l = 0; l < nl; ++l) pyr += Arena::pad((size_t)lw[l] * lh[l]);
+    for (int l = 0; l < nl; ++l) pyr += Arena::pad((size_t)lsd[l] * lh[l]);
     const size_t feat_bytes = (size_t)SORT_S * sizeof(vslam_feature);
-    const size_t desc_bytes = describe ? (size_t)nl * (Arena::pad((size_t)SORT_S * 4) + Arena::pad((size_t)SORT_S * 32)) + Arena::pad((size_t)w * h) + Arena::pad(VSLAM_ORB_PATTERN_BYTES) : 0;
+    const size_t desc_bytes = describe ? (size_t)nl * (Arena::pad((size_t)SORT_S * 4) + Arena::pad((size_t)SORT_S * 32)) + Arena::pad((size_t)bsd * h) + Arena::pad(VSLAM_ORB_PATTERN_BYTES) : 0;
     VSLAM_TRY(ws_reserve(ctx, orb_ws_bytes(1) + Arena::pad((size_t)stride * h) + pyr + (size_t)nl * Arena::pad(feat_bytes) + Arena::pad(64) + desc_bytes));
     Arena ar(ctx->ws);
     void *dws = ar.take<char>(orb_ws_bytes(1));
@@ -1238,14 +1355,14 @@ static vslam_status orb_run(vslam_ctx *ctx, const uint8_t *gray, int w, int h, i
     vslam_feature *dfeat[VSLAM_ORB_MAX_LEVELS];
     float *dangle[VSLAM_ORB_MAX_LEVELS];
     uint8_t *ddesc[VSLAM_ORB_MAX_LEVELS];
-    for (int l = 0; l < nl; ++l) dlev[l] = ar.take<uint8_t>((size_t)lw[l] * lh[l]);
+    for (int l = 0; l < nl; ++l) dlev[l] = ar.take<uint8_t>((size_t)lsd[l] * lh[l]);
     for (int l = 0; l < nl; ++l) dfeat[l] = ar.take<vslam_feature>(SORT_S);
     int32_t *dcount = ar.take<int32_t>(16);
     uint8_t *dblur = nullptr;
     int8_t *dpattern = nullptr;
     if (describe) {
         for (int l = 0; l < nl; ++l) { dangle[l] = ar.take<float>(SORT_S); ddesc[l] = ar.take<uint8_t>((size_t)SORT_S * 32); }
-        dblur = ar.take<uint8_t>((size_t)w * h);
+        dblur = ar.take<uint8_t>((size_t)bsd * h);
         dpattern = ar.take<int8_t>(VSLAM_ORB_PATTERN_BYTES);
         VSLAM_TRY(h2d(ctx, dpattern, pattern, VSLAM_ORB_PATTERN_BYTES));
     }
@@ -1256,16 +1373,16 @@ static vslam_status orb_run(vslam_ctx *ctx, const uint8_t *gray, int w, int h, i
         int iw = w, ih = h, is = stride;
         if (l > 0) {
             const uint8_t *prev = l == 1 ? dbase : dlev[l - 1];
-            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lw[l - 1];
-            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l]), dim3(256), 0, ctx->stream, prev, pw, ph, ps, (size_t)0, dlev[l], lw[l], lh[l], lw[l], (size_t)0);
-            VSLAM_HIP_TRY(ctx, hipGetLastError());
-            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lw[l];
+            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lsd[l - 1];
+            VSLAM_TRY(launch_resize(ctx, prev, pw, ph, ps, (size_t)0, dlev[l], lw[l], lh[l], lsd[l], (size_t)0, 1));
+            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lsd[l];
         }
         VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, 0, 1, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
                                    dfeat[l], SORT_S, dcount + l, dws));
         if (describe) {                                 // the blurred copy is reused level after level (stream order)
-            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, 0, dblur, iw, 0, 1));
-            VSLAM_TRY(launch_orb_describe(ctx, img, is, 0, dblur, iw, 0, iw, ih, 1, dfeat[l], dcount + l, SORT_S, dpattern, dangle[l], ddesc[l]));
+            const int bs_l = (iw + 15) & ~15;
+            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, 0, dblur, bs_l, 0, 1));
+            VSLAM_TRY(launch_orb_describe(ctx, img, is, 0, dblur, bs_l, 0, iw, ih, 1, dfeat[l], dcount + l, SORT_S, dpattern, dangle[l], ddesc[l]));
         }
     }
     int32_t hc[16] = {0};
@@ -1399,13 +1516,16 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
     // per level room for the budget plus ties at the cut
     OrbPackArgs pa;
     size_t bytes = orb_ws_bytes(frames) + Arena::pad((size_t)VSLAM_ORB_MAX_LEVELS * frames * 4) + Arena::pad(VSLAM_ORB_PATTERN_BYTES);
+    int lsd[VSLAM_ORB_MAX_LEVELS];                       // row strides of the library's own level images: multiples of 16 bytes
+    for (int l = 0; l < nl; ++l) lsd[l] = (lw[l] + 15) & ~15;
+    const int bsd = (w + 15) & ~15;
     for (int l = 0; l < nl; ++l) {
         pa.cap_l[l] = std::min(SORT_S, lf[l] + 1024);
-        if (l > 0) bytes += Arena::pad((size_t)frames * lw[l] * lh[l]);
+        if (l > 0) bytes += Arena::pad((size_t)frames * lsd[l] * lh[l]);
         bytes += Arena::pad((size_t)frames * pa.cap_l[l] * sizeof(vslam_feature));
         if (describe) bytes += Arena::pad((size_t)frames * pa.cap_l[l] * 4) + Arena::pad((size_t)frames * pa.cap_l[l] * 32);
     }
-    if (describe) bytes += Arena::pad((size_t)frames * w * h);
+    if (describe) bytes += Arena::pad((size_t)frames * bsd * h);
     VSLAM_TRY(ws_reserve(ctx, bytes));
     Arena ar(ctx->ws);
     void *dws = ar.take<char>(orb_ws_bytes(frames));
@@ -1416,11 +1536,11 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
     float *dangle[VSLAM_ORB_MAX_LEVELS] = {nullptr};
     uint8_t *ddesc[VSLAM_ORB_MAX_LEVELS] = {nullptr};
     for (int l = 0; l < nl; ++l) {
-        if (l > 0) dlev[l] = ar.take<uint8_t>((size_t)frames * lw[l] * lh[l]);
+        if (l > 0) dlev[l] = ar.take<uint8_t>((size_t)frames * lsd[l] * lh[l]);
         dfeat[l] = ar.take<vslam_feature>((size_t)frames * pa.cap_l[l]);
         if (describe) { dangle[l] = ar.take<float>((size_t)frames * pa.cap_l[l]); ddesc[l] = ar.take<uint8_t>((size_t)frames * pa.cap_l[l] * 32); }
     }
-    uint8_t *dblur = describe ? ar.take<uint8_t>((size_t)frames * w * h) : nullptr;
+    uint8_t *dblur = describe ? ar.take<uint8_t>((size_t)frames * bsd * h) : nullptr;
     hipStream_t s = ctx->stream;
     if (describe && !pattern) {
         int8_t own[VSLAM_ORB_PATTERN_BYTES];
@@ -1434,19 +1554,18 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
         size_t ifr = stride_frame;
         if (l > 0) {
             const uint8_t *prev = l == 1 ? gray : dlev[l - 1];
-            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lw[l - 1];
-            const size_t pf = l == 1 ? stride_frame : (size_t)lw[l - 1] * lh[l - 1];
-            ifr = (size_t)lw[l] * lh[l];
-            hipLaunchKernelGGL(resize_bilinear_kernel, dim3((lw[l] + 255) / 256, lh[l], frames), dim3(256), 0, s, prev, pw, ph, ps, pf, dlev[l], lw[l],
-                               lh[l], lw[l], ifr);
-            VSLAM_HIP_TRY(ctx, hipGetLastError());
-            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lw[l];
+            const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lsd[l - 1];
+            const size_t pf = l == 1 ? stride_frame : (size_t)lsd[l - 1] * lh[l - 1];
+            ifr = (size_t)lsd[l] * lh[l];
+            VSLAM_TRY(launch_resize(ctx, prev, pw, ph, ps, pf, dlev[l], lw[l], lh[l], lsd[l], ifr, frames));
+            img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lsd[l];
         }
         VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, ifr, frames, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
                                    dfeat[l], pa.cap_l[l], dcount + (size_t)l * frames, dws));
         if (describe) {
-            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, ifr, dblur, iw, (size_t)iw * ih, frames));
-            VSLAM_TRY(launch_orb_describe(ctx, img, is, ifr, dblur, iw, (size_t)iw * ih, iw, ih, frames, dfeat[l], dcount + (size_t)l * frames,
+            const int bs_l = (iw + 15) & ~15;
+            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, ifr, dblur, bs_l, (size_t)bs_l * ih, frames));
+            VSLAM_TRY(launch_orb_describe(ctx, img, is, ifr, dblur, bs_l, (size_t)bs_l * ih, iw, ih, frames, dfeat[l], dcount + (size_t)l * frames,
                                           pa.cap_l[l], pattern, dangle[l], ddesc[l]));
         }
         pa.feat[l] = dfeat[l]; pa.angle[l] = dangle[l]; pa.desc[l] = ddesc[l]; pa.scale[l] = ls[l];

@@ -68,6 +68,62 @@ __global__ __launch_bounds__(256) void gauss7_kernel(const uint8_t *src, int w, 
     }
 }
 
+// The same blur for images whose rows start on 4-byte boundaries (source and destination): whole words in and out, four
+// adjacent pixels per thread.  128 x 32 output pixels per workgroup; the row pass takes the four sums of a pixel quad
+// from three LDS words with byte-aligning shifts and two 4-way byte dot products per pixel (weights packed as bytes),
+// the column pass reads seven 16-byte rows of sums per quad.  Integer arithmetic: the same values as the kernel above.
+constexpr int G7W_W = 128, G7W_H = 32, G7W_PW = G7W_W / 4 + 2;        // words per staged source row (columns x0-4 .. x0+131)
+__global__ __launch_bounds__(256) void gauss7_words_kernel(const uint8_t *src, int w, int h, int sstride, size_t sframe, uint8_t *dst, int dstride,
+                                                           size_t dframe)
+{
+    __shared__ uint32_t px[(G7W_H + 6) * (G7W_PW + 1)];
+    __shared__ __align__(16) uint32_t hs[(G7W_H + 6) * G7W_W];
+    const int tid = threadIdx.x, x0 = blockIdx.x * G7W_W, y0 = blockIdx.y * G7W_H;
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    for (int i = tid; i < (G7W_H + 6) * G7W_PW; i += 256) {
+        const int r = i / G7W_PW, k = i - r * G7W_PW, gx = x0 - 4 + 4 * k;
+        const uint8_t *row = src + (size_t)reflect101(min(y0 + r - 3, h + 2), h) * sstride;
+        uint32_t v;
+        if (gx >= 0 && gx + 4 <= w) v = *reinterpret_cast<const uint32_t *>(row + gx);
+        else {
+            v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v |= (uint32_t)row[reflect101(min(gx + q, w + 2), w)] << (8 * q);
+        }
+        px[r * (G7W_PW + 1) + k] = v;
+    }
+    __syncthreads();
+    constexpr uint32_t W_LO = 18u | (34u << 8) | (49u << 16) | (54u << 24), W_HI = 49u | (34u << 8) | (18u << 16);
+    for (int i = tid; i < (G7W_H + 6) * (G7W_W / 4); i += 256) {
+        const int r = i / (G7W_W / 4), j = i - r * (G7W_W / 4);
+        const uint32_t *p = px + r * (G7W_PW + 1) + j;
+        const uint32_t a = p[0], b = p[1], c = p[2];          // columns x0+4j-4 .. x0+4j+7
+        uint4 o;
+        o.x = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 1), W_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 1), W_HI, 0u, false), false);
+        o.y = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 2), W_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 2), W_HI, 0u, false), false);
+        o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 3), W_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 3), W_HI, 0u, false), false);
+        o.w = __builtin_amdgcn_udot4(b, W_LO, __builtin_amdgcn_udot4(c, W_HI, 0u, false), false);
+        *reinterpret_cast<uint4 *>(hs + r * G7W_W + 4 * j) = o;
+    }
+    __syncthreads();
+    const unsigned wt[7] = {18u, 34u, 49u, 54u, 49u, 34u, 18u};
+    for (int i = tid; i < G7W_H * (G7W_W / 4); i += 256) {
+        const int r = i / (G7W_W / 4), j = i - r * (G7W_W / 4), x = x0 + 4 * j, y = y0 + r;
+        if (x >= w || y >= h) continue;
+        unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(hs + (r + t) * G7W_W + 4 * j);
+            a0 += wt[t] * v.x; a1 += wt[t] * v.y; a2 += wt[t] * v.z; a3 += wt[t] * v.w;
+        }
+        const uint32_t o = ((a0 + 32768u) >> 16) | (((a1 + 32768u) >> 16) << 8) | (((a2 + 32768u) >> 16) << 16) | (((a3 + 32768u) >> 16) << 24);
+        uint8_t *d = dst + (size_t)y * dstride + x;
+        if (x + 4 <= w) *reinterpret_cast<uint32_t *>(d) = o;
+        else for (int q = 0; q < w - x; ++q) d[q] = (uint8_t)(o >> (8 * q));
+    }
+}
+
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
     const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -170,8 +226,14 @@ void patch_half_widths(unsigned long long *lo, unsigned long long *hi)
 vslam_status launch_gauss7(vslam_ctx *ctx, const uint8_t *src, int w, int h, int sstride, size_t sframe, uint8_t *dst, int dstride,
                            size_t dframe, int frames)
 {
-    hipLaunchKernelGGL(gauss7_kernel, dim3((w + G7_W - 1) / G7_W, (h + G7_H - 1) / G7_H, frames), dim3(256), 0, ctx->stream, src, w, h, sstride,
-                       sframe, dst, dstride, dframe);
+    const bool words = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)sstride | (uintptr_t)dstride |
+                         (uintptr_t)sframe | (uintptr_t)dframe) & 3) == 0 && w >= 4;
+    if (words)
+        hipLaunchKernelGGL(gauss7_words_kernel, dim3((w + G7W_W - 1) / G7W_W, (h + G7W_H - 1) / G7W_H, frames), dim3(256), 0, ctx->stream, src, w, h,
+                           sstride, sframe, dst, dstride, dframe);
+    else
+        hipLaunchKernelGGL(gauss7_kernel, dim3((w + G7_W - 1) / G7_W, (h + G7_H - 1) / G7_H, frames), dim3(256), 0, ctx->stream, src, w, h, sstride,
+                           sframe, dst, dstride, dframe);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }

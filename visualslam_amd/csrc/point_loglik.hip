@@ -210,44 +210,59 @@ struct TermsArgs {
     int nblk;
 };
 
-__global__ __launch_bounds__(kThreads) void loglik_terms_kernel(CamK cam, TermsArgs t)
+// Sums each of v[0..31] over the 64 lanes of the wavefront in 32 exchanges instead of 6 per value: at every step a lane
+// keeps half of its values and hands the other half to the partner that keeps those (offsets 32, 16, 8, 4, 2), so the
+// number of values per lane halves as the number of lanes per sum doubles; a last exchange joins the two lanes of a pair.
+// Lane l returns the total of v[l >> 1].  Fixed order of additions.
+VSLAM_DEV double wave_sum32(const double (&v)[32], int lane)
+{
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4, h1 = lane & 2;
+    double a[16], b[8], c[4], d[2];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a[m] = (h5 ? v[m + 16] : v[m]) + __shfl_xor(h5 ? v[m] : v[m + 16], 32, 64);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) b[m] = (h4 ? a[m + 8] : a[m]) + __shfl_xor(h4 ? a[m] : a[m + 8], 16, 64);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) c[m] = (h3 ? b[m + 4] : b[m]) + __shfl_xor(h3 ? b[m] : b[m + 4], 8, 64);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) d[m] = (h2 ? c[m + 2] : c[m]) + __shfl_xor(h2 ? c[m] : c[m + 2], 4, 64);
+    double e = (h1 ? d[1] : d[0]) + __shfl_xor(h1 ? d[0] : d[1], 2, 64);
+    e += __shfl_xor(e, 1, 64);
+    return e;
+}
+
+// One wavefront per workgroup: 64 landmarks of one instance.  Nothing is shared between wavefronts (no barrier, no
+// LDS), a launch of B instances of L landmarks is B * ceil(L / 64) independent waves spread over the whole chip.
+constexpr int kTermThreads = 64;
+__global__ __launch_bounds__(kTermThreads) void loglik_terms_kernel(CamK cam, TermsArgs t)
 {
     const LoglikArgs &a = t.a;
-    const int b = blockIdx.y, tid = threadIdx.x, L = a.L;
+    const int b = blockIdx.y, lane = threadIdx.x, L = a.L;
     if (a.active && !a.active[b]) return;
     const double *x = a.x + (size_t)b * a.sx;
     const double *y = a.y + (size_t)b * a.sy;
     const uint8_t *vis = a.vis + (size_t)b * a.sv;
     double *g = a.g + (size_t)b * a.sg;
     double *rec = t.rec + (size_t)b * kRecFields * L;
-    const int j = blockIdx.x * kThreads + tid;
-    double acc[28];
+    const int j = blockIdx.x * kTermThreads + lane;
+    double acc[32];
 #pragma unroll
-    for (int i = 0; i < 28; ++i) acc[i] = 0.0;
-    if (blockIdx.x * kThreads + (tid & ~63) < L) {
-        const Pose pose = make_pose_wave(x + 6);
-        if (j < L) {
-            Terms tm;
-            landmark_terms<2>(cam, pose, x + 12 + 3 * j, y + 2 * j, vis[j] != 0, a.is2, a.lconst, tm);
-            acc[0] = tm.ell;
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    const Pose pose = make_pose_wave(x + 6);
+    if (j < L) {
+        Terms tm;
+        landmark_terms<2>(cam, pose, x + 12 + 3 * j, y + 2 * j, vis[j] != 0, a.is2, a.lconst, tm);
+        acc[0] = tm.ell;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { acc[1 + i] = tm.gr[i]; acc[4 + i] = tm.gT[i]; g[12 + 3 * j + i] = tm.gr[i]; }
+        for (int i = 0; i < 3; ++i) { acc[1 + i] = tm.gr[i]; acc[4 + i] = tm.gT[i]; g[12 + 3 * j + i] = tm.gr[i]; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { acc[7 + i] = tm.N[i]; acc[22 + i] = tm.F[i]; rec[(size_t)i * L + j] = tm.N[i]; }
+        for (int i = 0; i < 6; ++i) { acc[7 + i] = tm.N[i]; acc[22 + i] = tm.F[i]; rec[(size_t)i * L + j] = tm.N[i]; }
 #pragma unroll
-            for (int i = 0; i < 9; ++i) { acc[13 + i] = tm.E[i]; rec[(size_t)(6 + i) * L + j] = tm.E[i]; }
-            if (a.code) a.code[(size_t)b * L + j] = tm.code;
-        }
+        for (int i = 0; i < 9; ++i) { acc[13 + i] = tm.E[i]; rec[(size_t)(6 + i) * L + j] = tm.E[i]; }
+        if (a.code) a.code[(size_t)b * L + j] = tm.code;
     }
-    __shared__ double red[kThreads / 64][28];
-#pragma unroll
-    for (int i = 0; i < 28; ++i) acc[i] = wave_sum(acc[i]);
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 28; ++i) red[tid >> 6][i] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 28) t.part[((size_t)b * t.nblk + blockIdx.x) * 28 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    const double tot = wave_sum32(acc, lane);
+    if (!(lane & 1) && (lane >> 1) < 28) t.part[((size_t)b * t.nblk + blockIdx.x) * 28 + (lane >> 1)] = tot;
 }
 
 // value of H[row][column 12+3j+i] on its non-zero rows, from the records
@@ -390,8 +405,9 @@ static int pick_panel(int L, int batch)
 
 // Scratch of the entry point that allocates nothing: the records and per-block pose sums of the
 // two-launch form for at most kStaticLandmarks landmarks over all instances of a call and
-// kStaticBlocks (instance, 256-landmark block) pairs.  One copy per GPU, held until the process ends.
-constexpr size_t kStaticLandmarks = 81920, kStaticBlocks = 4096;
+// kStaticBlocks256 (instance, 256-landmark block) pairs (the sums are kept per 64 landmarks: four times as many
+// slots).  One copy per GPU, held until the process ends.
+constexpr size_t kStaticLandmarks = 81920, kStaticBlocks256 = 4096, kStaticBlocks = 4 * kStaticBlocks256;    // blocks of 64 landmarks
 constexpr size_t kStaticRecDoubles = kStaticLandmarks * kRecFields, kStaticPartDoubles = kStaticBlocks * 28;
 static __device__ __align__(256) double scratch[kStaticRecDoubles + kStaticPartDoubles];
 // Device address of `scratch` per GPU (the array's name is a host-side stand-in, not a device address).
@@ -441,13 +457,13 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
         const int slices = (int)(((size_t)n * n * 8 + 127 + kSliceBytes - 1) / kSliceBytes) + 1;
         TermsArgs t;
         t.a = a;
-        t.nblk = (a.L + kThreads - 1) / kThreads;
+        t.nblk = (a.L + kTermThreads - 1) / kTermThreads;
         const size_t rec_doubles = (size_t)batch * kRecFields * a.L, part_doubles = (size_t)batch * t.nblk * 28;
         if (static_scratch) {
-            if ((size_t)batch * a.L > kStaticLandmarks || (size_t)batch * t.nblk > kStaticBlocks)
+            if ((size_t)batch * a.L > kStaticLandmarks || (size_t)batch * ((a.L + 255) / 256) > kStaticBlocks256)
                 return fail(ctx, VSLAM_ERR_CAPACITY,
-                            "point_loglik (no allocation): %d instances x %d landmarks exceed the static scratch (%zu landmarks, %zu blocks of %d)",
-                            batch, a.L, kStaticLandmarks, kStaticBlocks, kThreads);
+                            "point_loglik (no allocation): %d instances x %d landmarks exceed the static scratch (%zu landmarks, %zu blocks of 256)",
+                            batch, a.L, kStaticLandmarks, kStaticBlocks256);
             t.rec = static_scratch;                      // every word the kernels read is written first: nothing to clear
             t.part = static_scratch + kStaticRecDoubles;
         } else {
@@ -458,7 +474,7 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
         }
         const bool timed = ctx->time_kernels && ctx->tev[0];
         if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[0], ctx->stream));
-        hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), block, 0, ctx->stream, cam, t);
+        hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), dim3(kTermThreads), 0, ctx->stream, cam, t);
         if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[1], ctx->stream));
         const size_t lds = (size_t)((kSliceBytes / 8) / (3 * n) + 3) * kRecFields * sizeof(double);
         hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), block, lds, ctx->stream, t);
