@@ -44,6 +44,9 @@ struct vslam_ctx {
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last measurement update on the device route: ms in cost evaluations, trust-region
                                  // factorisations + solves, posterior factor, whole call; counts of evaluations and factorisations
     int trs_last = -1;           // route the last measurement update took (-1: none yet)
+    void *ring = nullptr;        // pinned ring of the pipelined triangular transfers
+    size_t ring_bytes = 0;
+    hipEvent_t ring_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool time_kernels = false;   // measurement aid: events around the two kernels of the batched log-likelihood
     hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
     bool tev_recorded = false;
@@ -96,6 +99,14 @@ vslam_status h2d(vslam_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
 vslam_status d2h(vslam_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 vslam_status h2d_2d(vslam_ctx *ctx, void *dst_dev, size_t dpitch, const void *src_host, size_t spitch, size_t width, size_t height);
 vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *src_dev, size_t spitch, size_t width, size_t height);
+// Large upper-triangular factors between a caller's pageable matrix and device memory: only the columns' upper parts
+// cross PCIe, in column blocks through a ring of pinned buffers, while a few host threads move the blocks between the
+// ring and the caller's matrix (one contiguous pageable copy runs at about 11 GB/s, most of it the single-threaded
+// pass over the caller's pages).  d2h: the strict lower triangle of dst is set to zero.  h2d: the strict lower
+// triangle of the device matrix is left as it is (no kernel of the library reads it).  Both return when complete.
+constexpr int PIPELINED_COPY_MIN_N = 2048;      // below this one staged copy is as fast
+vslam_status d2h_upper_pipelined(vslam_ctx *ctx, double *dst_host, size_t ldd, const double *src_dev, size_t lds, int n);
+vslam_status h2d_upper_pipelined(vslam_ctx *ctx, double *dst_dev, size_t ldd, const double *src_host, size_t lds, int n);
 // Looks up, once per GPU, the device address of the static scratch array of the entry point that
 // allocates nothing (point_loglik.hip); called at context creation with the device current.
 vslam_status loglik_static_scratch_init(vslam_ctx *ctx);

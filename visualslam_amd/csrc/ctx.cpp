@@ -1,6 +1,9 @@
 // Context lifecycle, status strings, camera.xml reader.
 #include "common.hpp"
+#include <atomic>
 #include <mutex>
+#include <thread>
+#include <sched.h>
 
 #include <cmath>
 #include <cstdio>
@@ -149,6 +152,124 @@ vslam_status d2h_2d(vslam_ctx *ctx, void *dst_host, size_t dpitch, const void *s
 
 vslam_status h2d(vslam_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) { return h2d_2d(ctx, dst_dev, bytes, src_host, bytes, bytes, 1); }
 vslam_status d2h(vslam_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) { return d2h_2d(ctx, dst_host, bytes, src_dev, bytes, bytes, 1); }
+
+namespace {
+constexpr int RING_SLOTS = 8, RING_COLS = 64;
+
+vslam_status ring_reserve(vslam_ctx *ctx, int n)
+{
+    const size_t slot = (size_t)RING_COLS * n * 8, want = slot * RING_SLOTS;
+    if (ctx->ring_bytes < want) {
+        if (ctx->ring) { VSLAM_HIP_TRY(ctx, hipHostFree(ctx->ring)); ctx->ring = nullptr; ctx->ring_bytes = 0; }
+        hipError_t e = hipHostMalloc(&ctx->ring, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(ctx, VSLAM_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        ctx->ring_bytes = want;
+    }
+    for (int i = 0; i < RING_SLOTS; ++i)
+        if (!ctx->ring_ev[i]) VSLAM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming));
+    return VSLAM_OK;
+}
+
+int transfer_threads()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = (unsigned)c; }
+    int t = (int)(hw > 1 ? hw - 1 : 1);
+    return t > RING_SLOTS ? RING_SLOTS : t;
+}
+}  // namespace
+
+// Column block c holds columns [c * RING_COLS, ...) and, of each, rows 0 .. (end of the block): a rectangle in the ring.
+vslam_status d2h_upper_pipelined(vslam_ctx *ctx, double *dst, size_t ldd, const double *src, size_t lds, int n)
+{
+    VSLAM_TRY(ring_reserve(ctx, n));
+    const int nchunk = (n + RING_COLS - 1) / RING_COLS, W = transfer_threads();
+    const size_t slot_doubles = (size_t)RING_COLS * n;
+    std::vector<std::atomic<int>> recorded(nchunk), consumed(nchunk);
+    for (int c = 0; c < nchunk; ++c) { recorded[c].store(0); consumed[c].store(0); }
+    std::atomic<int> failed{0};
+    const int device = ctx->device;
+    auto worker = [&](int t) {
+        (void)hipSetDevice(device);
+        for (int c = t; c < nchunk; c += W) {
+            while (!recorded[c].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
+            if (hipEventSynchronize(ctx->ring_ev[c % RING_SLOTS]) != hipSuccess) { failed.store(1); consumed[c].store(1, std::memory_order_release); return; }
+            const int j0 = c * RING_COLS, j1 = std::min(n, j0 + RING_COLS), rows = j1;
+            const double *buf = static_cast<const double *>(ctx->ring) + (size_t)(c % RING_SLOTS) * slot_doubles;
+            for (int j = j0; j < j1; ++j) {
+                double *col = dst + (size_t)j * ldd;
+                std::memcpy(col, buf + (size_t)(j - j0) * rows, (size_t)(j + 1) * 8);
+                std::memset(col + j + 1, 0, (size_t)(n - j - 1) * 8);
+            }
+            consumed[c].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < W; ++t) pool.emplace_back(worker, t);
+    vslam_status st = VSLAM_OK;
+    for (int c = 0; c < nchunk && st == VSLAM_OK; ++c) {
+        if (c >= RING_SLOTS) while (!consumed[c - RING_SLOTS].load(std::memory_order_acquire)) std::this_thread::yield();
+        const int j0 = c * RING_COLS, j1 = std::min(n, j0 + RING_COLS), rows = j1;
+        double *buf = static_cast<double *>(ctx->ring) + (size_t)(c % RING_SLOTS) * slot_doubles;
+        hipError_t e = hipMemcpy2DAsync(buf, (size_t)rows * 8, src + (size_t)j0 * lds, lds * 8, (size_t)rows * 8, (size_t)(j1 - j0), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ev[c % RING_SLOTS], ctx->stream);
+        if (e != hipSuccess) { failed.store(1); st = fail(ctx, VSLAM_ERR_DEVICE, "pipelined copy to the host: %s", hipGetErrorString(e)); break; }
+        recorded[c].store(1, std::memory_order_release);
+    }
+    for (std::thread &th : pool) th.join();
+    if (st == VSLAM_OK && failed.load()) st = fail(ctx, VSLAM_ERR_DEVICE, "pipelined copy to the host: waiting for a block failed");
+    return st;
+}
+
+vslam_status h2d_upper_pipelined(vslam_ctx *ctx, double *dst, size_t ldd, const double *src, size_t lds, int n)
+{
+    VSLAM_TRY(ring_reserve(ctx, n));
+    const int nchunk = (n + RING_COLS - 1) / RING_COLS, W = transfer_threads();
+    const size_t slot_doubles = (size_t)RING_COLS * n;
+    std::vector<std::atomic<int>> packed(nchunk), sent(nchunk);
+    for (int c = 0; c < nchunk; ++c) { packed[c].store(0); sent[c].store(0); }
+    std::atomic<int> failed{0};
+    auto worker = [&](int t) {
+        for (int c = t; c < nchunk; c += W) {
+            // slot c % RING_SLOTS is free once the copy of chunk c - RING_SLOTS has left it
+            if (c >= RING_SLOTS) while (!sent[c - RING_SLOTS].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
+            const int j0 = c * RING_COLS, j1 = std::min(n, j0 + RING_COLS), rows = j1;
+            double *buf = static_cast<double *>(ctx->ring) + (size_t)(c % RING_SLOTS) * slot_doubles;
+            for (int j = j0; j < j1; ++j) {
+                std::memcpy(buf + (size_t)(j - j0) * rows, src + (size_t)j * lds, (size_t)(j + 1) * 8);
+                if (j + 1 < rows) std::memset(buf + (size_t)(j - j0) * rows + j + 1, 0, (size_t)(rows - j - 1) * 8);    // the block's own diagonal tile gets clean zeros
+            }
+            packed[c].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < W; ++t) pool.emplace_back(worker, t);
+    vslam_status st = VSLAM_OK;
+    for (int c = 0; c < nchunk && st == VSLAM_OK; ++c) {
+        while (!packed[c].load(std::memory_order_acquire)) std::this_thread::yield();
+        const int j0 = c * RING_COLS, j1 = std::min(n, j0 + RING_COLS), rows = j1;
+        const double *buf = static_cast<const double *>(ctx->ring) + (size_t)(c % RING_SLOTS) * slot_doubles;
+        hipError_t e = hipMemcpy2DAsync(dst + (size_t)j0 * ldd, ldd * 8, buf, (size_t)rows * 8, (size_t)rows * 8, (size_t)(j1 - j0), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ev[c % RING_SLOTS], ctx->stream);
+        // the slot may be refilled once this copy has read it: the sender waits for the copy RING_SLOTS - 2 chunks back
+        if (e == hipSuccess && c >= RING_SLOTS - 2) {
+            const int d = c - (RING_SLOTS - 2);
+            // chunk d's event slot is still its own: chunk d + RING_SLOTS has not been enqueued yet
+            e = hipEventSynchronize(ctx->ring_ev[d % RING_SLOTS]);
+            if (e == hipSuccess) sent[d].store(1, std::memory_order_release);
+        }
+        if (e != hipSuccess) { failed.store(1); st = fail(ctx, VSLAM_ERR_DEVICE, "pipelined copy to the device: %s", hipGetErrorString(e)); break; }
+    }
+    if (st == VSLAM_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = fail(ctx, VSLAM_ERR_DEVICE, "pipelined copy to the device: %s", hipGetErrorString(e));
+    }
+    for (int c = 0; c < nchunk; ++c) sent[c].store(1, std::memory_order_release);
+    failed.store(st != VSLAM_OK);
+    for (std::thread &th : pool) th.join();
+    return st;
+}
 
 vslam_status side_stream_init(vslam_ctx *ctx)
 {
@@ -336,6 +457,8 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->potf_dinv) (void)hipFree(ctx->potf_dinv);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ring) (void)hipHostFree(ctx->ring);
+    for (int i = 0; i < 8; ++i) if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 3; ++i) if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);

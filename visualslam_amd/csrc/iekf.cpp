@@ -176,7 +176,9 @@ extern "C" vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vsla
     cost_carve(ctx->ws, n, &c);
     const size_t nn = (size_t)n * n;
     VSLAM_TRY(h2d(ctx, c.mu, mu, n * 8));
-    VSLAM_TRY(h2d_2d(ctx, c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
+    // a large factor crosses PCIe as its upper triangle only, in column blocks packed by several host threads
+    if (n >= PIPELINED_COPY_MIN_N) VSLAM_TRY(h2d_upper_pipelined(ctx, c.S, (size_t)n, S, (size_t)ldS, n));
+    else VSLAM_TRY(h2d_2d(ctx, c.S, (size_t)n * 8, S, (size_t)ldS * 8, (size_t)n * 8, n));
     VSLAM_TRY(h2d(ctx, c.y, y, 2 * c.L * 8));
     VSLAM_TRY(h2d(ctx, c.vis, visible, c.L));
 
