@@ -534,10 +534,12 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     VSLAM_TRY(accept());
     int ret = 1, it;
     const bool trace = getenv("VSLAM_TRS_TRACE") != nullptr;       // diagnostic: the multipliers tried, per iteration
+    double warm_lam = 0.0;                                         // where the next search starts after an indefinite Hessian
     for (it = 0; it < 50; ++it) {
         // ---- trust-region subproblem, src/fmin.cpp:40-131, by the multiplier search of trs_search.hpp ----
         TrsSlot ts;
         ts.Delta = Delta;
+        if (warm_lam > 0.0) trs_warm_start(ts, warm_lam);
         for (bool first = true;; first = false) {
             if (trace) std::fprintf(stderr, "  iteration %d: Delta %.6g, factorisation at multiplier %.10g\n", it, Delta, ts.lam);
             VSLAM_TRY(factor_and_step(ts.lam));
@@ -561,6 +563,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
             if (next == TRS_DONE) break;
             if (next == TRS_REFACTOR_LAST) { VSLAM_TRY(factor_and_step(ts.lam)); break; }      // its verdict arrives with the dot products below
         }
+        warm_lam = ts.indefinite ? ts.lam : 0.0;
         // ---- src/fmin.hpp:54-105 ----
         if (n >= MV_SLABS) {                           // Hp = Hcur * p; the factor in w.U is spent, its memory takes the slab sums
             hipLaunchKernelGGL(matvec_slab_kernel, dim3((n + 63) / 64, MV_SLABS), dim3(256), 0, s, w.Hcur, n, n, w.p, w.U);

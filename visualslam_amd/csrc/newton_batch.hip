@@ -381,7 +381,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     std::vector<double> Delta(Bt, 1.0), lam(Bt, 0.0), hd((size_t)BK_DOTS * Bt, 0.0);
     // per filter
     std::vector<int> act(B, 1), acc(B, 0), ret(B, 1), its(B, MAX_ITERATIONS), stat(B, 0), done(B, 0), itb(B, 0), rej(B, 0), cur(B, 0);
-    std::vector<double> f(B, 0.0), fn(B, 0.0);
+    std::vector<double> f(B, 0.0), fn(B, 0.0), warm(B, 0.0);      // warm: where a filter's next search starts after an indefinite Hessian
     std::vector<std::vector<int>> ahead(B);                     // slots holding the filter's next subproblems, nearest first
 
     // One workgroup per matrix either way: the chain form of tri.hip where its blocks fit LDS (VSLAM_BANK_TRSV_OLD=1 keeps
@@ -543,7 +543,11 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         std::vector<int> Q(Bt, 0), R(Bt, 0), last(Bt, 0), failed(Bt, 0), scratch(Bt, 0);
         std::vector<double> piv(Bt, 0.0);
         bool info_dirty = false;
-        for (int sl = 0; sl < Bt; ++sl) ts[sl].Delta = Delta[sl];
+        for (int sl = 0; sl < Bt; ++sl) {
+            ts[sl].Delta = Delta[sl];
+            const int fb = sl < B ? sl : map[sl];                                       // the filter a slot solved ahead belongs to
+            if (trs[sl] && fb >= 0 && warm[fb] > 0.0) { trs_warm_start(ts[sl], warm[fb]); lam[sl] = ts[sl].lam; }
+        }
         VSLAM_TRY(send_mask(trs, true));
         VSLAM_TRY(factor_and_step());
         VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
@@ -599,6 +603,8 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 lam[sl] = ts[sl].lam; R[sl] = 1; last[sl] = next == TRS_REFACTOR_LAST;
             }
         }
+        for (int b = 0; b < B; ++b)
+            if (trs[b]) warm[b] = ts[b].indefinite ? ts[b].lam : 0.0;
         // ---- src/fmin.hpp:54-105: predicted decrease and the trial point of every slot ----
         VSLAM_TRY(send_mask(trs));
         if (nlisted > 0) {                             // Hpv = Hcur * p

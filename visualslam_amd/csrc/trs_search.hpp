@@ -72,6 +72,11 @@ inline bool trs_model_step(double m2, double m3, double m4, double m5, double De
 // to 1e-10 relative the step taken from that ff moves p by less than that: the search stops without it.
 inline bool trs_settled(double ff, double Delta) { return std::fabs(ff) * Delta < 1e-10; }
 
+// A filter whose last subproblem met an indefinite Hessian starts its next one at the multiplier that one ended with
+// instead of at zero (where the factorisation would fail first and be repaired pivot by pivot); if the Hessian has
+// become positive definite meanwhile the search comes back down to zero by itself.
+inline void trs_warm_start(TrsSlot &s, double lam_prev) { if (lam_prev > 0.0 && std::isfinite(lam_prev)) s.lam = lam_prev; }
+
 // The factorisation at s.lam failed; `pivot` is its first non-positive pivot.
 inline TrsNext trs_after_failure(TrsSlot &s, double pivot)
 {
@@ -102,6 +107,7 @@ inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, doub
     if (!(pn > 0.0) || !std::isfinite(pn)) return TRS_GIVE_UP;
     const double ff = 1.0 / D - 1.0 / pn;
     if (trs_settled(ff, D)) return TRS_DONE;
+    if (s.lam == 0.0 && !s.indefinite && pn <= D) return TRS_DONE;      // a search started above zero (trs_warm_start) came back to the interior Newton step
     const bool conv = std::fabs(ff) < sqrteps;
     if (pn > D) { if (s.lam > s.left) s.left = s.lam; }
     else if (s.lam < s.hi) s.hi = s.lam;
@@ -109,6 +115,8 @@ inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, doub
     double d = 0.0, next;
     if (trs_model_step(m2, m3, m4, m5, D, &d)) next = s.lam + d;
     else next = s.lam - ff / (-m3 / (pn * pn * pn));                    // the reference's Newton step (src/fmin.cpp:121-123)
+    // a search that started above zero and finds the root at or below zero has the plain Newton step left to try
+    if (!s.indefinite && s.left < 0.0 && s.lo == 0.0 && !(next > 0.0)) { ++s.steps; s.lam = 0.0; return TRS_REFACTOR; }
     // the root lies in (max(left, lo), hi)
     const double lower = std::fmax(s.left >= 0.0 ? s.left : 0.0, s.lo);
     const bool lower_open = s.left >= 0.0 || s.indefinite;              // the bound itself is not a candidate
