@@ -382,6 +382,12 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     // per filter
     std::vector<int> act(B, 1), acc(B, 0), ret(B, 1), its(B, MAX_ITERATIONS), stat(B, 0), done(B, 0), itb(B, 0), rej(B, 0), cur(B, 0);
     std::vector<double> f(B, 0.0), fn(B, 0.0), warm(B, 0.0);      // warm: where a filter's next search starts after an indefinite Hessian
+    // A filter whose step was rejected faces the same Hessian and gradient with a smaller radius: its factor U and step p
+    // of the last search are still in its slot, |p| exceeds the new radius (0.25 |p| at most), so the new search needs no
+    // factorisation at zero -- it continues from the moments at that factor (and seeds the subproblems solved ahead).
+    std::vector<TrsSlot> ts_last(B);
+    std::vector<int> have_factor(B, 0);
+    const bool continue_rejected = !getenv("VSLAM_BANK_NO_CONTINUE");
     std::vector<std::vector<int>> ahead(B);                     // slots holding the filter's next subproblems, nearest first
 
     // One workgroup per matrix either way: the chain form of tri.hip where its blocks fit LDS (VSLAM_BANK_TRSV_OLD=1 keeps
@@ -543,18 +549,32 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
         std::vector<int> Q(Bt, 0), R(Bt, 0), last(Bt, 0), failed(Bt, 0), scratch(Bt, 0);
         std::vector<double> piv(Bt, 0.0);
         bool info_dirty = false;
+        std::vector<int> first(Bt, 0), seed(Bt, 0), waiting(Bt, 0);
         for (int sl = 0; sl < Bt; ++sl) {
             ts[sl].Delta = Delta[sl];
-            const int fb = sl < B ? sl : map[sl];                                       // the filter a slot solved ahead belongs to
-            if (trs[sl] && fb >= 0 && warm[fb] > 0.0) { trs_warm_start(ts[sl], warm[fb]); lam[sl] = ts[sl].lam; }
-        }
-        VSLAM_TRY(send_mask(trs, true));
-        VSLAM_TRY(factor_and_step());
-        VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
-        for (int sl = 0; sl < Bt; ++sl) {
             if (!trs[sl]) continue;
-            if (hinfo[sl]) failed[sl] = 1;                                               // H itself is not positive definite
-            else if (!trs_interior(ts[sl], hd[(size_t)BK_DOTS * sl])) Q[sl] = 1;          // the Newton step leaves the region
+            const int fb = sl < B ? sl : map[sl];                                       // the filter a slot solved ahead belongs to
+            if (continue_rejected && fb >= 0 && rej[fb] && have_factor[fb]) {
+                if (sl < B) {
+                    ts[sl] = ts_last[fb];
+                    ts[sl].Delta = Delta[sl]; ts[sl].left = ts[sl].lam; ts[sl].hi = std::numeric_limits<double>::infinity();
+                    ts[sl].steps = 0; ts[sl].fails = 0; ts[sl].bump = 0.0;
+                    lam[sl] = ts[sl].lam; Q[sl] = 1; seed[sl] = 1;
+                } else waiting[sl] = 1;                                                  // seeded when its filter's moments arrive
+                continue;
+            }
+            first[sl] = 1;
+            if (fb >= 0 && warm[fb] > 0.0) { trs_warm_start(ts[sl], warm[fb]); lam[sl] = ts[sl].lam; }
+        }
+        if (any(first)) {
+            VSLAM_TRY(send_mask(first, true));
+            VSLAM_TRY(factor_and_step());
+            VSLAM_TRY(dots(w.p, w.p, nullptr, nullptr, nullptr, nullptr));
+            for (int sl = 0; sl < Bt; ++sl) {
+                if (!first[sl]) continue;
+                if (hinfo[sl]) failed[sl] = 1;                                           // H itself is not positive definite
+                else if (!trs_interior(ts[sl], hd[(size_t)BK_DOTS * sl])) Q[sl] = 1;      // the Newton step leaves the region
+            }
         }
         for (int kk = 0; kk < 80; ++kk) {
             if (any(failed)) {
@@ -597,14 +617,29 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 if (!trs[sl]) continue;
                 if (hinfo[sl]) { failed[sl] = 1; continue; }
                 const double *h4 = &hd[(size_t)BK_DOTS * sl];
+                if (seed[sl]) {
+                    // the same moments start the filter's subproblems solved ahead, each at the model's root for its own radius
+                    seed[sl] = 0;
+                    for (int v : ahead[sl]) {
+                        if (!waiting[v] || !trs[v]) continue;
+                        waiting[v] = 0;
+                        ts[v] = ts[sl];
+                        ts[v].Delta = Delta[v];
+                        const TrsNext nv = trs_after_solve(ts[v], h4[0], h4[1], h4[2], h4[3]);
+                        if (nv == TRS_GIVE_UP || nv == TRS_DONE) { ts[v] = TrsSlot(); ts[v].Delta = Delta[v]; lam[v] = 0.0; R[v] = 1; last[v] = 0; continue; }   // back to a search from zero
+                        lam[v] = ts[v].lam; R[v] = 1; last[v] = nv == TRS_REFACTOR_LAST;
+                    }
+                }
                 const TrsNext next = trs_after_solve(ts[sl], h4[0], h4[1], h4[2], h4[3]);
                 if (next == TRS_GIVE_UP) { drop_failed(scratch, sl); continue; }
                 if (next == TRS_DONE) continue;
                 lam[sl] = ts[sl].lam; R[sl] = 1; last[sl] = next == TRS_REFACTOR_LAST;
             }
         }
+        for (int sl = B; sl < Bt; ++sl)
+            if (waiting[sl]) drop_failed(scratch, sl);              // never seeded (its filter left the bank on the way)
         for (int b = 0; b < B; ++b)
-            if (trs[b]) warm[b] = ts[b].indefinite ? ts[b].lam : 0.0;
+            if (trs[b]) { warm[b] = ts[b].indefinite ? ts[b].lam : 0.0; ts_last[b] = ts[b]; have_factor[b] = 1; }
         // ---- src/fmin.hpp:54-105: predicted decrease and the trial point of every slot ----
         VSLAM_TRY(send_mask(trs));
         if (nlisted > 0) {                             // Hpv = Hcur * p
