@@ -363,30 +363,30 @@ vslam_status potrf_upper_dev(vslam_ctx *ctx, double *A, int n, int lda, int *inf
     return potrf_upper_batch_dev(ctx, A, n, lda, 0, 1, info, nullptr);
 }
 
-// out[i] = a_i . b_i for up to four vector pairs of length n (null pairs give 0).  One workgroup.  out[4] carries
+// out[i] = a_i . b_i for up to six vector pairs of length n (null pairs give 0).  One workgroup.  out[6] carries
 // *info (the factorisation's verdict travels to the host with the dot products).
-struct DotArgs { const double *a[4]; const double *b[4]; };
+struct DotArgs { const double *a[6]; const double *b[6]; };
 __global__ __launch_bounds__(1024) void dots_kernel(DotArgs d, int n, double *out, const int *info)
 {
-    __shared__ double red[4][16];
+    __shared__ double red[6][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int i = tid; i < n; i += 1024)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 6; ++q)
             if (d.a[q]) acc[q] += d.a[q][i] * d.b[q][i];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
         double v = acc[q];
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0) red[q][wave] = v;
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < 6) {
         double sum = 0.0;
         for (int w = 0; w < 16; ++w) sum += red[tid][w];
         out[tid] = sum;
-        if (tid == 0) out[4] = info ? (double)*info : 0.0;
+        if (tid == 0) out[6] = info ? (double)*info : 0.0;
     }
 }
 
@@ -471,7 +471,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     const double eps = std::numeric_limits<double>::epsilon();
     const int nb = (n + 255) / 256;
     int evals = 0, factorisations = 0;
-    double hd[5];
+    double hd[8];
     int hinfo = 0;
     *status_out = 0;
     // Wall-clock split of the call for the bench's breakdown; every phase below ends at a stream synchronisation
@@ -484,14 +484,16 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     auto phase_to = [&](double &acc) { acc += ms_since(t_phase); t_phase = clk::now(); };
 
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2,
-                    const double *a3 = nullptr, const double *b3 = nullptr) -> vslam_status {
+                    const double *a3 = nullptr, const double *b3 = nullptr, const double *a4 = nullptr, const double *b4 = nullptr,
+                    const double *a5 = nullptr, const double *b5 = nullptr) -> vslam_status {
         DotArgs d;
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = a3; d.b[3] = b3;
+        d.a[4] = a4; d.b[4] = b4; d.a[5] = a5; d.b[5] = b5;
         hipLaunchKernelGGL(dots_kernel, dim3(1), dim3(1024), 0, s, d, n, w.dots, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
-        VSLAM_TRY(d2h(ctx, hd, w.dots, 5 * 8));
+        VSLAM_TRY(d2h(ctx, hd, w.dots, 7 * 8));
         VSLAM_TRY(stream_sync(ctx));
-        hinfo = (int)hd[4];
+        hinfo = (int)hd[6];
         return VSLAM_OK;
     };
     // moments of the multiplier search (trs_search.hpp) at the current factor: |p|^2, |U^-T p|^2, |U^-1 U^-T p|^2, |U^-T U^-1 U^-T p|^2
@@ -499,7 +501,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.p, w.q));
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, false, w.q, w.t));
         VSLAM_TRY(trsv_upper_dev(ctx, w.U, n, n, true, w.t, w.spare));
-        return dots(w.p, w.p, w.q, w.q, w.t, w.t, w.spare, w.spare);
+        return dots(w.p, w.p, w.q, w.q, w.t, w.t, w.spare, w.spare, w.gcur, w.gcur, w.gcur, w.p);
     };
     // U^T U = Hcur + lam I;  p = -(Hcur + lam I)^-1 gcur
     auto factor_and_step = [&](double lam) -> vslam_status {
@@ -558,7 +560,7 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
                 if (trs_interior(ts, hd[0])) break;                 // the Newton step lies inside the region
                 VSLAM_TRY(moments());
             }
-            const TrsNext next = trs_after_solve(ts, hd[0], hd[1], hd[2], hd[3]);
+            const TrsNext next = trs_after_solve(ts, hd[0], hd[1], hd[2], hd[3], hd[4], -hd[5]);
             if (next == TRS_GIVE_UP) { *status_out = 1; return VSLAM_OK; }
             if (next == TRS_DONE) break;
             if (next == TRS_REFACTOR_LAST) { VSLAM_TRY(factor_and_step(ts.lam)); break; }      // its verdict arrives with the dot products below

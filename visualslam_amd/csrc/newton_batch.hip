@@ -125,27 +125,28 @@ __global__ __launch_bounds__(BK_T) void bk_trsv_kernel(const double *S, int ldS,
     for (int i = tid; i < n; i += BK_T) out[(size_t)b * n + i] = scale * z[i];
 }
 
-// out[b][q] = a_q[b] . b_q[b], q < 4 (null pairs give 0); one workgroup per active instance.  out[b][4] = info[b].
-constexpr int BK_DOTS = 8;                       // doubles per slot in the result
-struct BkDotArgs { const double *a[4]; const double *b[4]; };
+// out[b][q] = a_q[b] . b_q[b], q < 6 (null pairs give 0); one workgroup per active instance.  out[b][6] = info[b].
+constexpr int BK_DOTS = 8, BK_NDOT = 6;          // doubles per slot in the result; dot products among them
+struct BkDotArgs { const double *a[BK_NDOT]; const double *b[BK_NDOT]; };
 __global__ __launch_bounds__(BK_T) void bk_dots_kernel(BkDotArgs d, int n, double *out, const int *active, const int *info)
 {
-    __shared__ double red[4][BK_T / 64];
+    __shared__ double red[BK_NDOT][BK_T / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (info && tid == 0) out[(size_t)b * BK_DOTS + 4] = (double)info[b];      // every slot's factorisation flag travels with the dot products
+    if (info && tid == 0) out[(size_t)b * BK_DOTS + 6] = (double)info[b];      // every slot's factorisation flag travels with the dot products
     if (active && !active[b]) return;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[BK_NDOT] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int i = tid; i < n; i += BK_T)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < BK_NDOT; ++q)
             if (d.a[q]) acc[q] += d.a[q][(size_t)b * n + i] * d.b[q][(size_t)b * n + i];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < BK_NDOT; ++q) {
+        if (!d.a[q]) continue;
         const double v = wave_sum(acc[q]);
         if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
     __syncthreads();
-    if (tid < 4) out[(size_t)b * BK_DOTS + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
+    if (tid < BK_NDOT) out[(size_t)b * BK_DOTS + tid] = d.a[tid] ? ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3] : 0.0;
 }
 
 // out[b] = a * x[b] + c * y[b] over vectors of length n (y may be null), active instances only
@@ -419,14 +420,16 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
     auto any = [&](const std::vector<int> &h) { return std::any_of(h.begin(), h.end(), [](int v) { return v != 0; }); };
     // results of bk_dots_kernel and the factorisation flags of all slots
     auto dots = [&](const double *a0, const double *b0, const double *a1, const double *b1, const double *a2, const double *b2,
-                    const double *a3 = nullptr, const double *b3 = nullptr) -> vslam_status {
+                    const double *a3 = nullptr, const double *b3 = nullptr, const double *a4 = nullptr, const double *b4 = nullptr,
+                    const double *a5 = nullptr, const double *b5 = nullptr) -> vslam_status {
         BkDotArgs d;
         d.a[0] = a0; d.b[0] = b0; d.a[1] = a1; d.b[1] = b1; d.a[2] = a2; d.b[2] = b2; d.a[3] = a3; d.b[3] = b3;
+        d.a[4] = a4; d.b[4] = b4; d.a[5] = a5; d.b[5] = b5;
         hipLaunchKernelGGL(bk_dots_kernel, dim3(Bt), dim3(BK_T), 0, s, d, n, w.dots, w.active, (const int *)w.info);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         VSLAM_TRY(d2h(ctx, hd.data(), w.dots, (size_t)BK_DOTS * Bt * 8));
         VSLAM_TRY(stream_sync(ctx));
-        for (int sl = 0; sl < Bt; ++sl) hinfo[sl] = (int)hd[(size_t)BK_DOTS * sl + 4];
+        for (int sl = 0; sl < Bt; ++sl) hinfo[sl] = (int)hd[(size_t)BK_DOTS * sl + 6];
         return VSLAM_OK;
     };
     // for the slots of the mask on the device: U^T U = Hcur + lam I, p = -(Hcur + lam I)^-1 gcur
@@ -610,7 +613,7 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                 VSLAM_TRY(trsv(w.U, false, w.q, w.t, 1.0, w.active, Bt));
                 VSLAM_TRY(trsv(w.U, true, w.t, w.Hpv, 1.0, w.active, Bt));
             }
-            VSLAM_TRY(dots(w.p, w.p, w.q, w.q, w.t, w.t, w.Hpv, w.Hpv));
+            VSLAM_TRY(dots(w.p, w.p, w.q, w.q, w.t, w.t, w.Hpv, w.Hpv, w.gcur, w.gcur, w.gcur, w.p));
             for (int sl = 0; sl < Bt; ++sl) {
                 if (!Q[sl]) continue;
                 Q[sl] = 0;
@@ -625,12 +628,12 @@ static vslam_status iekf_bank_chunk(vslam_ctx *ctx, const CamK &k, double sigma,
                         waiting[v] = 0;
                         ts[v] = ts[sl];
                         ts[v].Delta = Delta[v];
-                        const TrsNext nv = trs_after_solve(ts[v], h4[0], h4[1], h4[2], h4[3]);
+                        const TrsNext nv = trs_after_solve(ts[v], h4[0], h4[1], h4[2], h4[3], h4[4], -h4[5]);
                         if (nv == TRS_GIVE_UP || nv == TRS_DONE) { ts[v] = TrsSlot(); ts[v].Delta = Delta[v]; lam[v] = 0.0; R[v] = 1; last[v] = 0; continue; }   // back to a search from zero
                         lam[v] = ts[v].lam; R[v] = 1; last[v] = nv == TRS_REFACTOR_LAST;
                     }
                 }
-                const TrsNext next = trs_after_solve(ts[sl], h4[0], h4[1], h4[2], h4[3]);
+                const TrsNext next = trs_after_solve(ts[sl], h4[0], h4[1], h4[2], h4[3], h4[4], -h4[5]);
                 if (next == TRS_GIVE_UP) { drop_failed(scratch, sl); continue; }
                 if (next == TRS_DONE) continue;
                 lam[sl] = ts[sl].lam; R[sl] = 1; last[sl] = next == TRS_REFACTOR_LAST;

@@ -66,6 +66,80 @@ inline bool trs_model_step(double m2, double m3, double m4, double m5, double De
     return std::isfinite(*d_out);
 }
 
+// The same with three nodes from six moments m_0 .. m_5, m_0 = |g|^2 and m_1 = -g'p being two dot products more: the low
+// moments carry the part of the gradient that lies along large eigenvalues, which the higher ones hardly see but which
+// decides |p| once the multiplier is large (collapsed trust regions): one factorisation fewer per subproblem there.
+// |p(lam + d)|^2 = sum_i w_i t_i^2 / (1 + d t_i)^2 over the rule's nodes t_i and weights w_i.
+inline bool trs_model_step3(const double (&m)[6], double Delta, double *d_out)
+{
+    for (double v : m) if (!(v > 0.0) || !std::isfinite(v)) return false;
+    const double s = m[1] / m[0];
+    double u[6], sp = 1.0;
+    for (int j = 0; j < 6; ++j) { u[j] = m[j] / (m[0] * sp); sp *= s; }
+    // Cholesky of the 3 x 3 Hankel matrix H[i][j] = u[i+j]: H = L L^T
+    double L[3][3] = {{0}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double acc = u[i + j];
+            for (int k = 0; k < j; ++k) acc -= L[i][k] * L[j][k];
+            if (i == j) { if (!(acc > 1e-14)) return false; L[i][i] = std::sqrt(acc); }
+            else L[i][j] = acc / L[j][j];
+        }
+    // J = L^-1 H1 L^-T with H1[i][j] = u[i+j+1]: symmetric, its eigenvalues are the nodes
+    double A[3][3], B[3][3];
+    for (int j = 0; j < 3; ++j)                       // A = L^-1 H1 (forward substitution, column by column)
+        for (int i = 0; i < 3; ++i) {
+            double acc = u[i + j + 1];
+            for (int k = 0; k < i; ++k) acc -= L[i][k] * A[k][j];
+            A[i][j] = acc / L[i][i];
+        }
+    for (int i = 0; i < 3; ++i)                       // B = A L^-T: rows of A solved against L
+        for (int j = 0; j < 3; ++j) {
+            double acc = A[i][j];
+            for (int k = 0; k < j; ++k) acc -= B[i][k] * L[j][k];
+            B[i][j] = acc / L[j][j];
+        }
+    double J[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) J[i][j] = 0.5 * (B[i][j] + B[j][i]);
+    for (int sweep = 0; sweep < 30; ++sweep) {        // cyclic Jacobi on the 3 x 3 matrix
+        const double off = std::fabs(J[0][1]) + std::fabs(J[0][2]) + std::fabs(J[1][2]);
+        if (off < 1e-18 * (std::fabs(J[0][0]) + std::fabs(J[1][1]) + std::fabs(J[2][2]))) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (J[p][q] == 0.0) continue;
+                const double th = (J[q][q] - J[p][p]) / (2.0 * J[p][q]);
+                const double tt = (th >= 0.0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+                const double c = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * c;
+                for (int k = 0; k < 3; ++k) { const double a = J[k][p], b = J[k][q]; J[k][p] = c * a - sn * b; J[k][q] = sn * a + c * b; }
+                for (int k = 0; k < 3; ++k) { const double a = J[p][k], b = J[q][k]; J[p][k] = c * a - sn * b; J[q][k] = sn * a + c * b; }
+            }
+    }
+    double t[3] = {J[0][0], J[1][1], J[2][2]};
+    if (!(t[0] > 0.0 && t[1] > 0.0 && t[2] > 0.0)) return false;
+    // weights from the first three moments: sum w = u0, sum w t = u1, sum w t^2 = u2 (Cramer)
+    const double d01 = t[1] - t[0], d02 = t[2] - t[0], d12 = t[2] - t[1];
+    if (!(std::fabs(d01 * d02 * d12) > 1e-14)) return false;
+    double w[3];
+    w[0] = (u[2] - (t[1] + t[2]) * u[1] + t[1] * t[2] * u[0]) / (d01 * d02);
+    w[1] = -(u[2] - (t[0] + t[2]) * u[1] + t[0] * t[2] * u[0]) / (d01 * d12);
+    w[2] = (u[2] - (t[0] + t[1]) * u[1] + t[0] * t[1] * u[0]) / (d02 * d12);
+    if (!(w[0] > 0.0 && w[1] > 0.0 && w[2] > 0.0)) return false;
+    // nodes and weights are those of the scaled variable t / s with unit total weight: |p(lam + d)|^2 = m0 s^2 f(d s)
+    const double tmax = std::fmax(t[0], std::fmax(t[1], t[2]));
+    const double target = Delta * Delta / (m[0] * s * s);
+    auto f = [&](double x) { double acc = 0.0; for (int i = 0; i < 3; ++i) { const double a = 1.0 + x * t[i]; acc += w[i] * t[i] * t[i] / (a * a); } return acc; };
+    double xl, xh;
+    if (f(0.0) > target) { xl = 0.0; xh = 1.0; int guard = 0; while (f(xh) > target && ++guard < 2000) xh *= 4.0; if (guard >= 2000) return false; }
+    else { xl = -(1.0 - 1e-12) / tmax; xh = 0.0; }
+    for (int it = 0; it < 200; ++it) {
+        const double xm = 0.5 * (xl + xh);
+        if (xm == xl || xm == xh) break;
+        if (f(xm) > target) xl = xm; else xh = xm;
+    }
+    *d_out = 0.5 * (xl + xh) / s;
+    return std::isfinite(*d_out);
+}
+
 // Stopping rule next to the reference's |ff| < sqrt(eps), ff = 1/Delta - 1/|p| (src/fmin.cpp:118-126): once the trust
 // region has shrunk (Delta << 1) that absolute test asks for more digits than ff has, and the reference then simply runs
 // its 20 Newton steps, which cost nothing in the eigenbasis; here each step is a factorisation.  When |p| matches Delta
@@ -100,7 +174,8 @@ inline TrsNext trs_after_failure(TrsSlot &s, double pivot)
 inline bool trs_interior(const TrsSlot &s, double m2) { return !s.indefinite && s.lam == 0.0 && std::sqrt(m2) <= s.Delta; }
 
 // ... and the three further moments: decides whether the search is over and where the next factorisation goes.
-inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, double m5)
+// m0 = |g|^2 and m1 = -g'p refine the model (trs_model_step3); pass 0 to leave them out.
+inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, double m5, double m0 = 0.0, double m1 = 0.0)
 {
     const double sqrteps = std::sqrt(std::numeric_limits<double>::epsilon());
     const double pn = std::sqrt(m2), D = s.Delta;
@@ -113,7 +188,9 @@ inline TrsNext trs_after_solve(TrsSlot &s, double m2, double m3, double m4, doub
     else if (s.lam < s.hi) s.hi = s.lam;
     s.bump = 0.0;
     double d = 0.0, next;
-    if (trs_model_step(m2, m3, m4, m5, D, &d)) next = s.lam + d;
+    const double m6[6] = {m0, m1, m2, m3, m4, m5};
+    if (m0 > 0.0 && m1 > 0.0 && trs_model_step3(m6, D, &d)) next = s.lam + d;
+    else if (trs_model_step(m2, m3, m4, m5, D, &d)) next = s.lam + d;
     else next = s.lam - ff / (-m3 / (pn * pn * pn));                    // the reference's Newton step (src/fmin.cpp:121-123)
     // a search that started above zero and finds the root at or below zero has the plain Newton step left to try
     if (!s.indefinite && s.left < 0.0 && s.lo == 0.0 && !(next > 0.0)) { ++s.steps; s.lam = 0.0; return TRS_REFACTOR; }
