@@ -44,6 +44,7 @@ def test_bank_matches_single_filter_updates(ctx, gcam, L, B):
             m1 = mup[b].cpu().numpy()
             S1 = Sp[b].cpu().numpy().T
             assert code[b] == c0
+            assert abs(int(iters[b]) - it0) <= 4
             if int(iters[b]) == it0:
                 assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
                 assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
@@ -255,3 +256,52 @@ def test_subproblems_solved_ahead_change_nothing_that_matters(ctx, gcam, monkeyp
         else:
             assert np.linalg.norm(np.linalg.solve(A0.T, m1[b] - m0[b])) <= 1e-6
             assert rel_err(A1.T @ A1, A0.T @ A0) <= 1e-6
+
+
+def test_subproblems_solved_ahead_are_consumed_and_counts_stay_near_the_oracle(ctx, gcam, ocam, monkeypatch, capfd):
+    """A bank in which the subproblems solved ahead are certainly used: fourteen filters that finish early beside two whose
+    last iterations are rejected steps (spare slots are only taken while filters and subproblems together stay within
+    half the bank).  The library's per-round trace must show spare slots in use and rounds with more than one evaluation
+    pass (a solution solved ahead was evaluated); every filter's iteration count stays within four of the CPU
+    restatement's and its posterior agrees with it."""
+    import re
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    L = 150
+    rng = np.random.default_rng(1)
+    tail = [syn.Scene(L, 9000 + i, dense_S=True) for i in range(2)]                 # several rejected steps at the end (checked below)
+    quick = syn.Scene(L, 9001, dense_S=True)
+    scs = tail + [quick] * 14
+    mus = [sc.x + np.concatenate([np.zeros(6), 1e-4 * rng.standard_normal(6), 1e-2 * rng.standard_normal(3 * L)]) for sc in tail]
+    mus += [quick.x.copy() for _ in range(14)]
+    mus = np.stack(mus)
+    dev = torch.device("cuda:0")
+    mu = torch.tensor(mus, device=dev)
+    S = torch.tensor(np.stack([np.ascontiguousarray(sc.S.T) for sc in scs]), device=dev)
+    y = torch.tensor(np.stack([sc.y for sc in scs]), device=dev)
+    vis = torch.tensor(np.stack([sc.visible for sc in scs]).astype(np.uint8), device=dev)
+    mup, Sp = torch.empty_like(mu), torch.empty_like(S)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("VSLAM_BANK_TRACE", "1")
+    capfd.readouterr()
+    code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, 7.0, mup, Sp)
+    torch.cuda.synchronize()
+    trace = capfd.readouterr().err
+    rounds = re.findall(r"bank round \\d+: (\\d+) filters \\+ (\\d+) subproblems solved ahead, (\\d+) multiplier steps, (\\d+) evaluation passes", trace)
+    assert rounds, trace
+    assert any(int(ahead) > 0 and int(passes) > 1 for _, ahead, _, passes in rounds), trace
+    assert not status.any()
+    for b in (0, 1, 2):                                                              # the two long filters and one of the quick ones
+        ret0, m0, S0, it0, _ = orc.measurement_update_iekf(mus[b], scs[b].S, scs[b].y, scs[b].visible, ocam, 7.0)
+        m1, S1 = mup[b].cpu().numpy(), Sp[b].cpu().numpy().T
+        assert code[b] == ret0 and abs(int(iters[b]) - it0) <= 4
+        if int(iters[b]) == it0:
+            assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-9
+        else:
+            assert np.linalg.norm(np.linalg.solve(S0.T, m1 - m0)) <= 1e-6
+            assert rel_err(S1.T @ S1, S0.T @ S0) <= 1e-6
+    assert max(int(iters[0]), int(iters[1])) >= 7
+    for b in range(3, 16):                                                           # identical filters, identical answers
+        assert iters[b] == iters[2] and torch.equal(mup[b], mup[2]) and torch.equal(Sp[b], Sp[2])
