@@ -288,7 +288,7 @@ def test_subproblems_solved_ahead_are_consumed_and_counts_stay_near_the_oracle(c
     code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, mu, S, y, vis, 7.0, mup, Sp)
     torch.cuda.synchronize()
     trace = capfd.readouterr().err
-    rounds = re.findall(r"bank round \\d+: (\\d+) filters \\+ (\\d+) subproblems solved ahead, (\\d+) multiplier steps, (\\d+) evaluation passes", trace)
+    rounds = re.findall(r"bank round \d+: (\d+) filters \+ (\d+) subproblems solved ahead, (\d+) multiplier steps, (\d+) evaluation passes", trace)
     assert rounds, trace
     assert any(int(ahead) > 0 and int(passes) > 1 for _, ahead, _, passes in rounds), trace
     assert not status.any()

@@ -25,6 +25,13 @@ def kernel_stats(db_path, csv_path):
     return {r[0]: {"calls": r[1], "avg_ns": r[3]} for r in rows}
 
 
+def median_ms(db_path, name_part):
+    """Median duration (ms) of the launches of the kernel whose name contains `name_part`."""
+    db = sqlite3.connect(db_path)
+    d = sorted(r[0] for r in db.execute("select end - start from kernels where name like ?", ("%" + name_part + "%",)))
+    return d[len(d) // 2] / 1e6 if d else None
+
+
 def trace_summary(db_path, txt_path, focus, reps):
     """Per-kernel totals over the last of `reps` equal repetitions in a kernel trace, the durations of the
     `focus` kernel and the idle gaps between its consecutive launches."""
@@ -94,6 +101,10 @@ def main():
         "workload": "512 instances, L=150, n=462, value+gradient+Hessian (one point_loglik call = terms + assemble kernels)",
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE taken as is; units KB",
         "kernels": kern, "hbm_bytes_per_launch": total, "algorithmic_bytes_per_launch": alg,
+        # duration of the same kernel in the kernel trace of bench.py taken by the same script: bench.py replays the
+        # byte counts above only while its own launches last this long
+        "assemble_kernel_avg_ms": median_ms(os.path.join(SRC, "bench", "bench_results.db"), "loglik_assemble_kernel"),
+        "terms_kernel_avg_ms": median_ms(os.path.join(SRC, "bench", "bench_results.db"), "loglik_terms_kernel"),
     }
     with open(os.path.join(DST, "traffic_point_loglik.json"), "w") as f:
         json.dump(traffic, f, indent=1)

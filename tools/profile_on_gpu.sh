@@ -20,7 +20,17 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUS
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_affine" -o bank_affine -- python3 "$R/tools/run_bank_affine.py" 512 150 3 > "$OUT/bank_affine.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/bank_iekf" -o bank_iekf -- python3 "$R/tools/run_iekf_bank.py" 150 512 --batched > "$OUT/bank_iekf.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/c4" -o c4 -- python3 "$R/tools/run_update.py" 2000 2 > "$OUT/c4.log" 2>&1 || echo "config-4 trace failed" > "$OUT/c4.failed"
+TAG="${1:-r03}"
+# front-end kernel trace and the SQ counter passes of the kernels the front end and the headline call spend their time in
+bash "$R/tools/trace_pass.sh" orb run_orb.py 64 3 > "$OUT/orb_trace.log" 2>&1 || echo "orb trace failed" > "$OUT/orb_trace.failed"
+bash "$R/tools/sq_pass.sh" loglik run_loglik.py 512 150 3 > "$OUT/sq_loglik.log" 2>&1 || echo "loglik sq pass failed" > "$OUT/sq_loglik.failed"
+bash "$R/tools/sq_pass.sh" fast9 run_fast9.py 64 3 > "$OUT/sq_fast9.log" 2>&1 || echo "fast9 sq pass failed" > "$OUT/sq_fast9.failed"
+bash "$R/tools/sq_pass.sh" orb run_orb.py 64 3 > "$OUT/sq_orb.log" 2>&1 || echo "orb sq pass failed" > "$OUT/sq_orb.failed"
+cd /tmp
+mkdir -p "$R/gpurun_out/profiles_out"
+for f in loglik fast9 orb; do [ -f "$R/gpurun_out/sq/$f.json" ] && cp "$R/gpurun_out/sq/$f.json" "$R/gpurun_out/profiles_out/${TAG}_${f}_sq_counters.json"; done
+[ -f "$R/gpurun_out/trace/orb_kernel_stats.csv" ] && cp "$R/gpurun_out/trace/orb_kernel_stats.csv" "$R/gpurun_out/profiles_out/${TAG}_orb_kernel_stats.csv"
 # the databases are too large to travel back: condensed here, summaries only are kept
-VSLAM_PROFILES_DST="$R/gpurun_out/profiles_out" python3 "$R/tools/condense_profiles.py" "${1:-r02}" || exit 1
+VSLAM_PROFILES_DST="$R/gpurun_out/profiles_out" python3 "$R/tools/condense_profiles.py" "$TAG" || exit 1
 rm -rf "$OUT"/*/
 ls "$R/gpurun_out/profiles_out"
