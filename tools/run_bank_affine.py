@@ -23,3 +23,10 @@ for _ in range(reps):
     api.affine_bundle_batch_dev(ctx, cam, mu, S, my, Sy)
 torch.cuda.synchronize()
 print("muY[0,:2]", my[0, :2].tolist())
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    api.affine_bundle_batch_dev(ctx, cam, mu, S, my, Sy)
+e1.record()
+torch.cuda.synchronize()
+print("ms per bank", e0.elapsed_time(e1) / reps)

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(256) void s_times_ct_kernel(const double *S, int n,
 }
 
 // dst[b] (m x m, ld m) = leading m x m block of src[b] (ld lds, stride_src entries apart)
+// dst = the upper triangle of the leading m x m block of src, zeros below the diagonal (src still holds reflectors there)
 __global__ void copy_block_batch_kernel(const double *src, int lds, size_t stride_src, double *dst, int m)
 {
     const int r = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (r < m) dst[(size_t)blockIdx.z * m * m + (size_t)c * m + r] = src[(size_t)blockIdx.z * stride_src + (size_t)c * lds + r];
+    if (r < m) dst[(size_t)blockIdx.z * m * m + (size_t)c * m + r] = r <= c ? src[(size_t)blockIdx.z * stride_src + (size_t)c * lds + r] : 0.0;
 }
 
 // mux_out[i] = mu[ny+i] + sum_k S2[k,i] t[k]   (src/gaussian.cpp:34)
@@ -313,7 +314,9 @@ extern "C" vslam_status vslam_affine_bundle_batch_dev(vslam_ctx *ctx, const vsla
     hipLaunchKernelGGL(bundle_jac_compact_kernel, dim3((L + 63) / 64, batch), dim3(64), 0, s, k, mux, L, layout, muy, code, rec);
     hipLaunchKernelGGL(s_times_ct_kernel, dim3((rows + 255) / 256, L, batch), dim3(256), 0, s, Sxx, n, n, rec, L, layout, dA, rows);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, per_A, batch, qws));
+    // rows n .. n+m-1 hold the diagonal noise factor: column c is zero below row n + c, and stays so under the reflectors of
+    // the columns before it
+    VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, per_A, batch, qws, n, false));
     hipLaunchKernelGGL(copy_block_batch_kernel, dim3((m + 255) / 256, m, batch), dim3(256), 0, s, dA, rows, per_A, Syy, m);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;

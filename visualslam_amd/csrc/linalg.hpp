@@ -69,7 +69,10 @@ vslam_status gemm_f64_on(vslam_ctx *ctx, const GemmDesc &d, hipStream_t stream);
 // Eigen sign convention) and the strict lower triangle is zero.  `ws` must
 // hold qr_ws_bytes(rows, cols, batch) bytes.
 size_t qr_ws_bytes(int rows, int cols, int batch);
-vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws);
+// band >= 0 promises A(i, c) == 0 for i > c + band (e.g. a diagonal block stacked under a dense one of `band` rows): panels
+// then stop at the band.  zero_lower = false leaves the reflectors below the diagonal for a caller who copies R out itself.
+vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws, int band = -1,
+                          bool zero_lower = true);
 
 // W = inverse of the upper-triangular S (n x n); strict lower part of W zeroed (zero_lower = false: only inside the
 // diagonal 64 x 64 blocks -- for a caller that reads W as a triangular operand and saves the pass).

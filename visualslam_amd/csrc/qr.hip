@@ -611,14 +611,23 @@ struct QrJob {
     QrBlockPlan pl;
     unsigned launches;       // launches of qr_block_kernel so far in this factorisation
     int ob;                  // reflectors per outer block (128, or what qr_block_kernel keeps resident)
+    int band;                // >= 0: A(i, c) == 0 for i > c + band on entry (a diagonal block under a dense one); -1: dense
     QrWs w;
 };
+
+// Rows of the panel at (j, j) with jb columns that can hold a non-zero: below a band the reflectors of the panel are zero
+// and so is everything they would change, so neither the factorisation nor the update of the later columns goes there.
+static inline int panel_rows(const QrJob &q, int j, int jb)
+{
+    const int mp = q.rows - j;
+    return (q.band >= 0 && q.band + jb < mp) ? q.band + jb : mp;
+}
 
 // Factors the jb-column panel whose origin is (j, j); T goes to Tdst.  Vout (optional) receives the
 // explicit reflectors, vzero rows above the panel cleared.
 static vslam_status qr_factor_panel(QrJob &q, int j, int jb, double *Tdst, double *Vout, int ldv, int vzero)
 {
-    const int mp = q.rows - j;
+    const int mp = panel_rows(q, j, jb);
     double *P = q.A + (size_t)j * q.lda + j;
     hipStream_t s = q.ctx->stream;
     if (q.use_block) {
@@ -654,7 +663,7 @@ static vslam_status qr_apply_panel(QrJob &q, int j, int jb, const double *Tsrc, 
     if (n2 <= 0) return VSLAM_OK;
     vslam_ctx *ctx = q.ctx;
     hipStream_t s = ctx->stream;
-    const int mp = q.rows - j, batch = q.batch;
+    const int mp = panel_rows(q, j, jb), batch = q.batch;
     double *P = q.A + (size_t)j * q.lda + j;
     double *A2 = P + (size_t)jb * q.lda;
     const int ksplit = pick_ksplit(mp, n2, batch);
@@ -946,20 +955,31 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
 
 // Factorisations whose workgroups wait for one another (qr_block_kernel with more than one workgroup per matrix) take the
 // GPU's turn (DeviceTurnGuard).
-static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws);
+static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws,
+                                       int band, bool zero_lower);
 
-vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
+// The band is used by the panel-by-panel form only (banks, short matrices): the tallest panel then has band + NB rows.
+static int tallest_panel(int rows, int cols, int batch, int band)
 {
-    QrBlockPlan pl;
-    const bool waits = rows >= 1 && cols >= 1 && batch >= 1 &&
-                       ((qr_block_plan(rows, batch, block_width(rows, cols, batch), &pl) && pl.G > 1) || coop_rows_per(rows, batch) > 0);
-    if (!waits) return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
-    DeviceTurnGuard turn(ctx);                        // queued behind the previous such factorisation or solve on this GPU
-    if (turn.status() != VSLAM_OK) return turn.status();
-    return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws);
+    if (band < 0 || use_outer_blocks(rows, cols, batch) || getenv("VSLAM_QR_NO_BAND")) return rows;
+    return band + NB < rows ? band + NB : rows;
 }
 
-static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws)
+vslam_status qr_upper_dev(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws, int band,
+                          bool zero_lower)
+{
+    QrBlockPlan pl;
+    const int tall = (rows >= 1 && cols >= 1 && batch >= 1) ? tallest_panel(rows, cols, batch, band) : rows;
+    const bool waits = rows >= 1 && cols >= 1 && batch >= 1 &&
+                       ((qr_block_plan(tall, batch, block_width(rows, cols, batch), &pl) && pl.G > 1) || coop_rows_per(rows, batch) > 0);
+    if (!waits) return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws, band, zero_lower);
+    DeviceTurnGuard turn(ctx);                        // queued behind the previous such factorisation or solve on this GPU
+    if (turn.status() != VSLAM_OK) return turn.status();
+    return qr_upper_dev_inner(ctx, A, rows, cols, lda, strideA, batch, ws, band, zero_lower);
+}
+
+static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws,
+                                       int band, bool zero_lower)
 {
     if (rows < 1 || cols < 1 || lda < rows) return fail(ctx, VSLAM_ERR_SHAPE, "qr: bad shape %dx%d ld %d", rows, cols, lda);
     if (batch < 1 || batch > 65535) return fail(ctx, VSLAM_ERR_SHAPE, "qr: batch=%d out of range", batch);
@@ -967,7 +987,9 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
     q.ctx = ctx; q.A = A; q.rows = rows; q.cols = cols; q.lda = lda; q.strideA = strideA; q.batch = batch;
     q.tbase = 0; q.rows_per = coop_rows_per(rows, batch);
     q.launches = 0; q.ob = OB;
-    q.use_block = qr_block_plan(rows, batch, block_width(rows, cols, batch), &q.pl) && !getenv("VSLAM_QR_COLUMNWISE");
+    const int tall = tallest_panel(rows, cols, batch, band);
+    q.band = tall < rows ? band : -1;
+    q.use_block = qr_block_plan(tall, batch, block_width(rows, cols, batch), &q.pl) && !getenv("VSLAM_QR_COLUMNWISE");
     qr_carve(ws, rows, cols, batch, &q.w);
     const int kmax = rows < cols ? rows : cols;
     hipStream_t s = ctx->stream;
@@ -1007,8 +1029,10 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
         VSLAM_TRY(qr_factor_panel(q, j0, jb, q.w.T, nullptr, 0, 0));
         VSLAM_TRY(qr_apply_panel(q, j0, jb, q.w.T, cols - j0 - jb));
     }
-    dim3 grid((rows + 255) / 256, cols, batch);
-    hipLaunchKernelGGL(zero_strict_lower_kernel, grid, dim3(256), 0, s, A, rows, cols, lda, strideA);
+    if (zero_lower) {
+        dim3 grid((rows + 255) / 256, cols, batch);
+        hipLaunchKernelGGL(zero_strict_lower_kernel, grid, dim3(256), 0, s, A, rows, cols, lda, strideA);
+    }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
