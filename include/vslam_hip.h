@@ -232,24 +232,34 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
  * and a solution is used when the radius the reference would set, 0.25 |p|, equals the one solved for to 1e-9
  * relative (VSLAM_BANK_SOLVE_AHEAD=0 in the environment switches this off; the work space grows by up to two
  * n x n matrices per filter for the spare slots).
- * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = its Hessian was not positive definite
- * at some iterate: its outputs are meaningless and the caller redoes that filter with
- * vslam_measurement_update_iekf.  Returns after the results are complete. */
+ * A Hessian that is not positive definite at some iterate is handled within the bank (see CHOLESKY below).
+ * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = a subproblem of filter b could not be finished from
+ * Cholesky factors (the hard case of the trust-region subproblem, a non-finite Hessian, or a posterior Hessian
+ * that is not positive definite): its outputs are meaningless and the caller redoes that filter with
+ * vslam_measurement_update_iekf, which has the eigenvalue route to fall back on.  Returns after the results are
+ * complete. */
 vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, const vslam_camera *cam, const double *mu,
                                                      const double *S, int n, int batch, const double *y,
                                                      const uint8_t *visible, double sigma, double *mu_post,
                                                      double *S_post, int32_t *fmin_code, int32_t *iters, int32_t *status);
 
 /* How vslam_measurement_update_iekf solves the trust-region subproblem of src/fmin.cpp:40-131.
- * CHOLESKY (default; no counterpart in the reference): while the Hessian is positive definite, from Cholesky
- *      factors on the device -- the same secular-equation Newton iteration (iterates equal to about 1e-10
- *      relative: see the stopping rule noted at vslam_measurement_update_iekf_batch_dev), no eigensolver; the
- *      posterior square root is the inverse of a triangular factor of the Hessian (equal to the reference's
- *      up to row signs).  An update that meets an indefinite Hessian is redone on the EIG route, so a caller
- *      who changes nothing gets this route with that fallback.
+ * CHOLESKY (default; no counterpart in the reference): from Cholesky factors of H + lambda I on the device, no
+ *      eigensolver.  The subproblem's solution is the reference's (the search for the multiplier ends with the
+ *      reference's test and its final step; steps agree to about 1e-10 relative: see the stopping rule noted at
+ *      vslam_measurement_update_iekf_batch_dev), but the multipliers tried on the way are chosen from a rational
+ *      model of |p(lambda)| built from a few triangular solves, not by the reference's Newton iteration, so fewer
+ *      factorisations are needed.  An indefinite Hessian shows as a failed factorisation whose first non-positive
+ *      pivot gives the next shift; the search then brackets the multiplier above -lambda_min as More & Sorensen's
+ *      safeguards do.  Only the hard case (no boundary solution above -lambda_min: the bracket collapses) and
+ *      non-finite input send the update to the EIG route, so a caller who changes nothing gets this route with
+ *      that fallback.  The posterior square root is the inverse of a triangular factor of the Hessian (equal to
+ *      the reference's up to row signs).  Iteration counts equal the reference's except where a decision of the
+ *      outer loop (accept / shrink on rho) is taken on rounding noise, i.e. in the last iterations of an update
+ *      whose steps have fallen below the resolution of the cost; the EIG route reproduces those counts.
  * EIG (opt-in, the reference's arithmetic step for step): from a symmetric eigendecomposition of the Hessian
  *      taken on the host at every accepted iterate (O(n^3) scalar work per iterate; 110 ms per update at 150
- *      landmarks against 10 ms, and not usable at 2,000). */
+ *      landmarks against 4.6 ms, and not usable at 2,000). */
 enum { VSLAM_TRS_EIG = 0, VSLAM_TRS_CHOLESKY = 1 };
 vslam_status vslam_ctx_set_trs_solver(vslam_ctx *ctx, int solver);
 /* Route the context's last measurement update actually took (VSLAM_TRS_CHOLESKY = device route,
