@@ -653,26 +653,48 @@ __device__ __forceinline__ int fast9_strength(const int (&d)[16])
     return max(best, -worst);
 }
 
+typedef short ft_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ft_short2 ft_even(uint32_t x) { return __builtin_bit_cast(ft_short2, __builtin_amdgcn_perm(x, x, 0x0c020c00u)); }   // bytes 0, 2 as two 16-bit values
+__device__ __forceinline__ ft_short2 ft_odd(uint32_t x) { return __builtin_bit_cast(ft_short2, __builtin_amdgcn_perm(x, x, 0x0c030c01u)); }    // bytes 1, 3
+__device__ __forceinline__ uint32_t ft_bits(ft_short2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ int ft_rank(unsigned long long m)        // active lanes below this one in the ballot m
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
 {
+    constexpr int FT_WPR = (FT_IW + 4) / 4;            // words per row of the tile image
+    constexpr int FT_GROUPS = (FT_SW + 3 + 3) / 4;     // aligned groups of four columns that cover the columns with a strength
     __shared__ __align__(4) uint8_t img[FT_IH][FT_IW + 4];
-    __shared__ int st[FT_SH][FT_SW + 1];
+    __shared__ __align__(4) uint8_t st[FT_SH][FT_SW + 2];              // strengths (<= 255), 0 = no corner
     constexpr int FT_STAGE = 512;                      // staged candidates per tile; the rare tile with more appends the rest one by one
     __shared__ uint64_t stage[FT_STAGE];
     __shared__ uint16_t queue[FT_SH * FT_SW];          // positions (lx | ly << 8) that passed both quick tests
-    __shared__ int lcnt, gbase, qn;
-    const int tid = threadIdx.x;
+    __shared__ uint16_t corners[FT_SH * FT_SW];        // ... of those, the ones with an arc of nine
+    __shared__ int lcnt, gbase, qn, cn;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int frame = blockIdx.x % a.frames, tile = blockIdx.x / a.frames;
     const int x0 = (tile % a.tiles_x) * FT_W, y0 = (tile / a.tiles_x) * FT_H;
     const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
-    const int w = a.w, h = a.h;
-    if (tid == 0) { lcnt = 0; qn = 0; }
-    if (((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)a.stride) & 3) == 0) {
+    const int w = a.w, h = a.h, t = a.threshold;
+    if (tid == 0) { lcnt = 0; qn = 0; cn = 0; }
+    for (int i = tid; i < (int)(sizeof(st) / 4); i += FT_T) reinterpret_cast<uint32_t *>(&st[0][0])[i] = 0u;
+    const bool words = ((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)a.stride) & 3) == 0;
+    // the tile with its halo and the ring of strengths lie wholly inside the image, at least 3 pixels from its sides
+    const bool inner = x0 >= 4 && y0 >= 4 && x0 + FT_W + 4 <= w && y0 + FT_H + 4 <= h;
+    if (words && inner) {
+        for (int idx = tid; idx < FT_IH * FT_WPR; idx += FT_T) {
+            const int ly = idx / FT_WPR, lw = idx - ly * FT_WPR;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(gray + (size_t)(y0 - 4 + ly) * a.stride + (x0 - 4));
+            *reinterpret_cast<uint32_t *>(&img[ly][4 * lw]) = lw < FT_IW / 4 ? src[lw] : 0u;
+        }
+    } else if (words) {
         // rows start on 4-byte boundaries and x0 - 4 is a multiple of 4: whole words, bytes past the image zeroed
-        for (int idx = tid; idx < FT_IH * (FT_IW / 4); idx += FT_T) {
-            const int ly = idx / (FT_IW / 4), lw = idx - ly * (FT_IW / 4), gx = x0 - 4 + 4 * lw, gy = y0 - 4 + ly;
+        for (int idx = tid; idx < FT_IH * FT_WPR; idx += FT_T) {
+            const int ly = idx / FT_WPR, lw = idx - ly * FT_WPR, gx = x0 - 4 + 4 * lw, gy = y0 - 4 + ly;
             uint32_t v = 0;
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
+            if (lw < FT_IW / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w) {
                 if (gx + 4 <= a.stride) v = *reinterpret_cast<const uint32_t *>(gray + (size_t)gy * a.stride + gx);
                 else for (int q = 0; q < 4 && gx + q < a.stride; ++q) v |= (uint32_t)gray[(size_t)gy * a.stride + gx + q] << (8 * q);
                 if (gx + 4 > w) v &= 0xffffffffu >> (8 * (gx + 4 - w));
@@ -680,57 +702,124 @@ __global__ __launch_bounds__(FT_T) void fast9_tile_kernel(FastArgs a)
             *reinterpret_cast<uint32_t *>(&img[ly][4 * lw]) = v;
         }
     } else {
-        for (int idx = tid; idx < FT_IH * FT_IW; idx += FT_T) {
-            const int ly = idx / FT_IW, lx = idx - ly * FT_IW, gx = x0 - 4 + lx, gy = y0 - 4 + ly;
-            img[ly][lx] = (gx >= 0 && gy >= 0 && gx < w && gy < h) ? gray[(size_t)gy * a.stride + gx] : (uint8_t)0;
+        for (int idx = tid; idx < FT_IH * (FT_IW + 4); idx += FT_T) {
+            const int ly = idx / (FT_IW + 4), lx = idx - ly * (FT_IW + 4), gx = x0 - 4 + lx, gy = y0 - 4 + ly;
+            img[ly][lx] = (lx < FT_IW && gx >= 0 && gy >= 0 && gx < w && gy < h) ? gray[(size_t)gy * a.stride + gx] : (uint8_t)0;
         }
     }
     __syncthreads();
-    // Strengths of the tile and its 1-pixel ring (FT_SW x FT_SH), in two passes.  Pass 1 -- every position: an arc of 9
-    // of the 16 ring pixels contains one pixel of every opposite pair, so the vertical pair rejects most pixels and the
-    // horizontal one most others; the few that pass both are queued in LDS.  Pass 2 -- the queue, densely packed: the
-    // full segment test.  (Evaluated in place, a wavefront pays for the full test whenever ONE of its 64 pixels needs
-    // it, which on textured frames is most wavefronts: 137 instructions per pixel against 30 + 250 per queued pixel.)
-    auto quick_at = [&](int lx, int ly) {
-        const int px = x0 - 1 + lx, py = y0 - 1 + ly;
-        bool pass = false;
-        if (px >= 3 && py >= 3 && px < w - 3 && py < h - 3) {
-            const int cy = ly + 3, cx = lx + 3, v = img[cy][cx], t = a.threshold;
-            const int q0 = img[cy + 3][cx] - v, q8 = img[cy - 3][cx] - v;
-            const bool up = max(q0, q8) > t, dn = min(q0, q8) < -t;
-            if (up || dn) {
-                const int q4 = img[cy][cx + 3] - v, q12 = img[cy][cx - 3] - v;
-                pass = (up && max(q4, q12) > t) || (dn && min(q4, q12) < -t);
-            }
+    // Strengths of the tile and its 1-pixel ring (FT_SW x FT_SH), in three passes.
+    // Pass 1 -- every position, four to a lane: an arc of 9 of the 16 ring pixels contains one pixel of every opposite
+    // pair, so the vertical pair rejects most pixels and the horizontal one most others.  A lane takes an aligned word of
+    // four centre pixels with the words three rows above and below and the two words shifted by three columns, and does
+    // the comparisons on pairs of 16-bit values (c + t < max(pair) or min(pair) < c - t, read off the sign bits of packed
+    // differences).  Positions that pass are appended to a queue in LDS.
+    // Pass 2 -- the queue, densely packed: sixteen ring pixels into two 16-bit masks (brighter than c + t, darker than
+    // c - t); a corner has nine contiguous bits in one of them.  Corners go to a second queue.
+    // Pass 3 -- the corners: the exact strength (best arc minimum), which only they need.
+    // (Evaluated in place, a wavefront pays for the full test whenever ONE of its 64 pixels needs it, which on textured
+    // frames is most wavefronts.)
+    const uint32_t *imgw = reinterpret_cast<const uint32_t *>(&img[0][0]);
+    for (int idx = tid; idx < FT_SH * FT_GROUPS; idx += FT_T) {
+        const int ly = idx / FT_GROUPS, k = idx - ly * FT_GROUPS;
+        const uint32_t *row = imgw + (ly + 3) * FT_WPR + k;
+        const uint32_t c = row[0], wl = k > 0 ? row[-1] : 0u, wr = row[1], up = row[-3 * FT_WPR], dn = row[3 * FT_WPR];
+        const uint32_t l3 = __builtin_amdgcn_alignbyte(c, wl, 1), r3 = __builtin_amdgcn_alignbyte(wr, c, 3);
+        const ft_short2 tt = {(short)t, (short)t};
+        uint32_t pe, po;
+        {
+            const ft_short2 cc = ft_even(c), ct = cc + tt, cm = cc - tt;
+            const ft_short2 u = ft_even(up), d = ft_even(dn), l = ft_even(l3), r = ft_even(r3);
+            const ft_short2 xu = ct - __builtin_elementwise_max(u, d), xd = __builtin_elementwise_min(u, d) - cm;
+            const ft_short2 yu = ct - __builtin_elementwise_max(l, r), yd = __builtin_elementwise_min(l, r) - cm;
+            pe = (ft_bits(xu) & ft_bits(yu)) | (ft_bits(xd) & ft_bits(yd));
         }
-        st[ly][lx] = 0;
-        // wave-aggregated append: one LDS atomic per wavefront
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            const int lane = tid & 63, leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&qn, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (pass) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(lx | (ly << 8));
+        {
+            const ft_short2 cc = ft_odd(c), ct = cc + tt, cm = cc - tt;
+            const ft_short2 u = ft_odd(up), d = ft_odd(dn), l = ft_odd(l3), r = ft_odd(r3);
+            const ft_short2 xu = ct - __builtin_elementwise_max(u, d), xd = __builtin_elementwise_min(u, d) - cm;
+            const ft_short2 yu = ct - __builtin_elementwise_max(l, r), yd = __builtin_elementwise_min(l, r) - cm;
+            po = (ft_bits(xu) & ft_bits(yu)) | (ft_bits(xd) & ft_bits(yd));
         }
-    };
-    for (int ly = tid >> 6; ly < FT_SH; ly += FT_T / 64) quick_at(tid & 63, ly);
-    if (tid < 2 * FT_SH) quick_at(FT_W + (tid & 1), tid >> 1);        // the two remaining columns (the ballot counts the active lanes only)
+        // pixel j of the group: column lx = 4 k + j - 3 of the strength array, image column x0 - 4 + 4 k + j
+        uint32_t m4 = ((pe >> 15) & 0x10001u) | ((po >> 14) & 0x20002u);
+        m4 = (m4 | (m4 >> 14)) & 0xfu;                                          // bit j: pixel j passed
+        if (inner) m4 &= k == 0 ? 0x8u : (k == FT_GROUPS - 1 ? 0x1u : 0xfu);  // columns 0 .. FT_SW - 1 of the strength array
+        else {
+            const int py = y0 - 1 + ly, gx = x0 - 4 + 4 * k;
+            const int jlo = max(max(3 - 4 * k, 3 - gx), 0), jhi = min(min(FT_SW + 2 - 4 * k, w - 4 - gx), 3);
+            m4 &= (py >= 3 && py < h - 3 && jhi >= jlo) ? ((2u << jhi) - 1u) & ~((1u << jlo) - 1u) : 0u;
+        }
+        if (m4) {
+            // one LDS atomic per lane with a survivor (about one lane in five), written out: the compiler would turn a plain
+            // atomicAdd of a lane-dependent value into a loop over the active lanes
+            int at;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(at) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)&qn), "v"(__popc(m4)) : "memory");
+            const int pos = (4 * k - 3) + (ly << 8);
+            if (m4 & 1u) queue[at++] = (uint16_t)pos;
+            if (m4 & 2u) queue[at++] = (uint16_t)(pos + 1);
+            if (m4 & 4u) queue[at++] = (uint16_t)(pos + 2);
+            if (m4 & 8u) queue[at] = (uint16_t)(pos + 3);
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < qn; i += FT_T) {
-        const int lx = queue[i] & 255, ly = queue[i] >> 8;
-        const int cy = ly + 3, cx = lx + 3, v = img[cy][cx], t = a.threshold;
+    const int nq = qn;
+    for (int i0 = 0; i0 < nq; i0 += FT_T) {
+        const int i = i0 + tid;
+        bool corner = false;
+        int pos = 0;
+        if (i < nq) {
+            pos = queue[i];
+            const int lx = pos & 255, ly = pos >> 8;
+            const uint8_t *c = &img[ly + 3][lx + 3];
+            constexpr int R = FT_IW + 4;
+            const int v = c[0], tv = v + t, vm = v - t;
+            uint32_t mb = 0, md = 0;
+            auto ring = [&](int off) {
+                const int I = c[off];
+                mb = __builtin_amdgcn_alignbit(mb, (uint32_t)(tv - I), 31);        // shift in "I > v + t"
+                md = __builtin_amdgcn_alignbit(md, (uint32_t)(I - vm), 31);        // shift in "I < v - t"
+            };
+            ring(3 * R);      ring(3 * R + 1);  ring(2 * R + 2);  ring(R + 3);
+            ring(3);          ring(-R + 3);     ring(-2 * R + 2); ring(-3 * R + 1);
+            ring(-3 * R);     ring(-3 * R - 1); ring(-2 * R - 2); ring(-R - 3);
+            ring(-3);         ring(R - 3);      ring(2 * R - 2);  ring(3 * R - 1);
+            auto nine = [](uint32_t m) {                                            // nine contiguous bits of the circular 16-bit mask
+                const uint32_t x = m | (m << 16);
+                const uint32_t r2 = x & (x >> 1), r4 = r2 & (r2 >> 2), r8 = r4 & (r4 >> 4);
+                return (r8 & (x >> 8)) & 0xffffu;
+            };
+            corner = (nine(mb) | nine(md)) != 0u;
+        }
+        const unsigned long long m = __ballot(corner);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&cn, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (corner) corners[base + ft_rank(m)] = (uint16_t)pos;
+        }
+    }
+    __syncthreads();
+    const int nc = cn;
+    for (int i = tid; i < nc; i += FT_T) {
+        const int lx = corners[i] & 255, ly = corners[i] >> 8;
+        const int cy = ly + 3, cx = lx + 3, v = img[cy][cx];
         int d[16];
         d[0] = img[cy + 3][cx] - v;       d[1] = img[cy + 3][cx + 1] - v;  d[2] = img[cy + 2][cx + 2] - v;  d[3] = img[cy + 1][cx + 3] - v;
         d[4] = img[cy][cx + 3] - v;       d[5] = img[cy - 1][cx + 3] - v;  d[6] = img[cy - 2][cx + 2] - v;  d[7] = img[cy - 3][cx + 1] - v;
         d[8] = img[cy - 3][cx] - v;       d[9] = img[cy - 3][cx - 1] - v;  d[10] = img[cy - 2][cx - 2] - v; d[11] = img[cy - 1][cx - 3] - v;
         d[12] = img[cy][cx - 3] - v;      d[13] = img[cy + 1][cx - 3] - v; d[14] = img[cy + 2][cx - 2] - v; d[15] = img[cy + 3][cx - 1] - v;
         const int sv = fast9_strength(d);
-        if (sv > t) st[ly][lx] = sv;
+        if (sv > t) st[ly][lx] = (uint8_t)sv;
     }
     __syncthreads();
-    for (int ly = tid >> 6; ly < FT_H; ly += FT_T / 64) {
-        const int lx = tid & 63, px = x0 + lx, py = y0 + ly;
+    // suppression and output: the corners of the tile proper (the ring only serves as neighbours)
+    for (int i = tid; i < nc; i += FT_T) {
+        const int lx = (corners[i] & 255) - 1, ly = (corners[i] >> 8) - 1;
+        if (lx < 0 || ly < 0 || lx >= FT_W || ly >= FT_H) continue;
+        const int px = x0 + lx, py = y0 + ly;
         if (px >= w || py >= h) continue;
         if (px < a.border || py < a.border || px >= w - a.border || py >= h - a.border) continue;
         const int s = st[ly + 1][lx + 1];
