@@ -208,6 +208,7 @@ struct TermsArgs {
     double *rec;       // [batch][kRecFields][L]
     double *part;      // [batch][nblk][28]
     int nblk;
+    int slice_bytes;   // bytes of H per workgroup of the assemble kernel (a multiple of 128)
 };
 
 // Sums each of v[0..31] over the 64 lanes of the wavefront in 32 exchanges instead of 6 per value: at every step a lane
@@ -344,17 +345,59 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         else g[tid] = tid < 6 ? 0.0 : (tid < 9 ? -s : s);
     }
     // this block's slice of the flat element range [0, n*n), cut at absolute 128-byte lines
-    const size_t total = (size_t)n * n;
+    const uint32_t total = (uint32_t)n * (uint32_t)n;              // element indices fit 32 bits (the launcher checks n < 65536)
     const uintptr_t base = reinterpret_cast<uintptr_t>(H);
     const uintptr_t line0 = base & ~uintptr_t(127);
-    const uintptr_t lo = line0 + (uintptr_t)blockIdx.x * kSliceBytes, hi = lo + kSliceBytes;
-    size_t e0 = lo <= base ? 0 : (size_t)((lo - base) >> 3);
-    size_t e1 = hi <= base ? 0 : (size_t)((hi - base) >> 3);
+    const uintptr_t lo = line0 + (uintptr_t)blockIdx.x * (uintptr_t)t.slice_bytes, hi = lo + (uintptr_t)t.slice_bytes;
+    uint32_t e0 = lo <= base ? 0u : (uint32_t)((lo - base) >> 3);
+    uint32_t e1 = hi <= base ? 0u : (uint32_t)((hi - base) >> 3);
     if (e1 > total) e1 = total;
     if (e0 >= e1) return;
+    const int cA = (int)(e0 / n), cB = (int)((e1 - 1) / n);
+    if (cA >= 12) {
+        // The slice holds landmark columns only (all but the first two slices of an instance).  A column 12 + 3 j + i
+        // has nine non-zero rows: 6..11 (the pose rows: -N[.][i] and E[i][.]) and the three rows d0 = 3 (col / 3) .. d0 + 2
+        // of its own landmark (N[.][i]).  They are staged per column, in row order, so that an element finds its value
+        // with two comparisons and one LDS read and no wavefront takes a slow path for the sake of a few lanes.
+        double *scol = srec;                                                    // [column of the slice][9]
+        for (int q = tid; q < (cB - cA + 1) * 9; q += kThreads) {
+            const int cl = q / 9, f = q - 9 * cl, col = cA + cl, j = (col - 12) / 3, i = col - 12 - 3 * j;
+            scol[q] = f < 3 ? -rec_N(rec, L, j, f, i) : (f < 6 ? rec[(size_t)(6 + i * 3 + (f - 3)) * L + j] : rec_N(rec, L, j, f - 6, i));
+        }
+        __syncthreads();
+        auto in_column = [&](const double *cv, int d0, int row) -> double {
+            const int t = row - d0;
+            const bool ok = (unsigned)(row - 6) < 6u || (unsigned)t < 3u;
+            return ok ? cv[row < 12 ? row - 6 : t + 6] : 0.0;
+        };
+        auto value = [&](int col, int row) -> double { return in_column(scol + (col - cA) * 9, 3 * (col / 3), row); };
+        uint32_t e = e0;
+        if ((base + ((uintptr_t)e << 3)) & 8) {                   // head single (only possible at the instance start, which lies in a pose column)
+            if (tid == 0) { const int col = (int)(e / n), row = (int)(e - (uint32_t)col * n); H[e] = value(col, row); }
+            ++e;
+        }
+        const uint32_t npair = (e1 - e) >> 1;
+        const uint32_t idx = e + 2u * (uint32_t)tid;
+        int col = (int)(idx / n), row = (int)(idx - (uint32_t)col * n);
+        for (uint32_t k = tid; k < npair; k += kThreads) {
+            const double *cv = scol + (col - cA) * 9;
+            const int d0 = 3 * (int)(((unsigned)col * 43691u) >> 17);           // 3 * (col / 3) for col < 65536
+            double2 o;
+            o.x = in_column(cv, d0, row);
+            o.y = row + 1 == n ? 0.0 : in_column(cv, d0, row + 1);              // a pair that ends in row 0 of the next column: zero there
+            *reinterpret_cast<double2 *>(H + e + 2 * k) = o;
+            row += 2 * kThreads;
+            while (row >= n) { row -= n; ++col; }
+        }
+        if (((e1 - e) & 1) && tid == 0) {              // tail single (only at the instance end)
+            const uint32_t el = e1 - 1;
+            const int c = (int)(el / n), r = (int)(el - (uint32_t)c * n);
+            H[el] = value(c, r);
+        }
+        return;
+    }
     int j_lo = 0;
     {
-        const int cA = (int)(e0 / n), cB = (int)((e1 - 1) / n);
         if (cB >= 12) {
             j_lo = cA >= 12 ? (cA - 12) / 3 : 0;
             const int j_hi = (cB - 12) / 3;
@@ -366,15 +409,15 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         __syncthreads();
     }
     // head single if the slice starts on an odd 8-byte boundary (only possible at the instance start)
-    size_t e = e0;
-    if ((base + (e << 3)) & 8) {
-        if (tid == 0) { const int col = (int)(e / n), row = (int)(e - (size_t)col * n); H[e] = assemble_value(t, rec, part_b, srec, j_lo, col, row); }
+    uint32_t e = e0;
+    if ((base + ((uintptr_t)e << 3)) & 8) {
+        if (tid == 0) { const int col = (int)(e / n), row = (int)(e - (uint32_t)col * n); H[e] = assemble_value(t, rec, part_b, srec, j_lo, col, row); }
         ++e;
     }
-    const size_t npair = (e1 - e) >> 1;
-    size_t idx = e + 2 * (size_t)tid;
-    int col = (int)(idx / n), row = (int)(idx - (size_t)col * n);
-    for (size_t k = tid; k < npair; k += kThreads) {
+    const uint32_t npair = (e1 - e) >> 1;
+    const uint32_t idx = e + 2u * (uint32_t)tid;
+    int col = (int)(idx / n), row = (int)(idx - (uint32_t)col * n);
+    for (uint32_t k = tid; k < npair; k += kThreads) {
         int col2 = col, row2 = row + 1;
         if (row2 == n) { row2 = 0; ++col2; }
         double2 o = make_double2(0.0, 0.0);
@@ -387,8 +430,8 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         while (row >= n) { row -= n; ++col; }
     }
     if (((e1 - e) & 1) && tid == 0) {                  // tail single (only at the instance end)
-        const size_t el = e1 - 1;
-        const int c = (int)(el / n), r = (int)(el - (size_t)c * n);
+        const uint32_t el = e1 - 1;
+        const int c = (int)(el / n), r = (int)(el - (uint32_t)c * n);
         H[el] = assemble_value(t, rec, part_b, srec, j_lo, c, r);
     }
 }
@@ -452,11 +495,14 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
     const int panels = (a.L + a.P - 1) / a.P;
     dim3 block(kThreads);
     // With the static scratch every Hessian goes through the two-launch form (the one that needs scratch).
-    const bool two_launch = H && ldH == n && a.L > 0 && (static_scratch || (size_t)batch * n * n * 8 >= ((size_t)32 << 20));
+    const bool two_launch = H && ldH == n && a.L > 0 && n < 65536 && (static_scratch || (size_t)batch * n * n * 8 >= ((size_t)32 << 20));
     if (two_launch) {
-        const int slices = (int)(((size_t)n * n * 8 + 127 + kSliceBytes - 1) / kSliceBytes) + 1;
+        int slice_bytes = kSliceBytes;
+        if (const char *e = getenv("VSLAM_LOGLIK_SLICE")) { const int v = atoi(e); if (v >= 1024 && v <= (1 << 20)) slice_bytes = v & ~127; }     // A/B runs
+        const int slices = (int)(((size_t)n * n * 8 + 127 + slice_bytes - 1) / slice_bytes) + 1;
         TermsArgs t;
         t.a = a;
+        t.slice_bytes = slice_bytes;
         t.nblk = (a.L + kTermThreads - 1) / kTermThreads;
         const size_t rec_doubles = (size_t)batch * kRecFields * a.L, part_doubles = (size_t)batch * t.nblk * 28;
         if (static_scratch) {
@@ -476,7 +522,10 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
         if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[0], ctx->stream));
         hipLaunchKernelGGL(loglik_terms_kernel, dim3(t.nblk, batch), dim3(kTermThreads), 0, ctx->stream, cam, t);
         if (timed) VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[1], ctx->stream));
-        const size_t lds = (size_t)((kSliceBytes / 8) / (3 * n) + 3) * kRecFields * sizeof(double);
+        // records of the landmarks of a slice (the slices that reach into the pose columns) or nine values per column of it
+        const size_t lds_rec = (size_t)((slice_bytes / 8) / (3 * n) + 3) * kRecFields, lds_col = (size_t)((slice_bytes / 8) / n + 2) * 9;
+        const size_t lds = (lds_rec > lds_col ? lds_rec : lds_col) * sizeof(double);
+
         hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), block, lds, ctx->stream, t);
         if (timed) { VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[2], ctx->stream)); ctx->tev_recorded = true; }
     } else if (H) {
