@@ -141,6 +141,7 @@ struct CholUpdArgs {
     const double *Csrc;            // optional: the old values of the trailing block come from here (same layout, strideSrc apart)
     size_t strideSrc;              //   plus a shift of the diagonal -- the first update of a factorisation that does not
     const double *lamv; double lam; //   start from a copy of the matrix (lamv: one shift per matrix, else lam)
+    int strip;                     // 1: only the first block row of C (tiles (0, 0 .. )), the launch has one workgroup per tile column
 };
 constexpr int UKC = 16, ULD = UKC + 2;
 // linear id -> tile (tm <= tn) of the upper triangle, column by column
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256, 4) void chol_update_kernel(CholUpdArgs g)
     if (b < 0) return;
     const int T = (g.N + CB - 1) / CB, tri = T * (T + 1) / 2;
     int tile_m, tile_n;
-    if (bx < tri) upper_tile(bx, &tile_m, &tile_n);
+    if (g.strip) { tile_m = 0; tile_n = bx; }
+    else if (bx < tri) upper_tile(bx, &tile_m, &tile_n);
     else { tile_n = T; tile_m = bx - tri; }           // the right-hand side in a tile column of its own
     const int m0 = tile_m * CB, n0 = tile_n * CB;
     const double *P = g.P + (size_t)b * g.strideA;
@@ -331,25 +333,48 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
     double *dinv = ctx->potf_dinv;
     const int extra = rhs ? 1 : 0;                    // the right-hand side rides along as column n
     bool factored = false;                            // the diagonal block of this step was factored by the previous update
-    for (int j0 = 0; j0 < n; j0 += CB) {
+    // Banks take the trailing update two block rows at a time: after the row panel of block row k only block row k + 1 is
+    // updated (a strip of tiles, whose first one factors the next diagonal block), its row panel is solved, and the rest of
+    // the trailing matrix then receives both block rows in one pass with K = 128 -- the read-modify-write of C, which is
+    // what a bank's update launches spend their time on, happens once per 128 columns.  One matrix gains nothing from it
+    // (its launches are as long as the chain of diagonal blocks) and keeps the one-level form, bit for bit.
+    const bool two_level = batch >= 16 && !getenv("VSLAM_POTRF_ONE_LEVEL");
+    auto launch_trsm = [&](int j0, int rest) {
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, listed ? 1 : 0, dinv, (size_t)1024,
+                           rhs, stride_rhs);
+    };
+    // C = the trailing block whose origin is (c0, c0), N columns; P = the K finished rows from row p0 on above it
+    auto launch_update = [&](int p0, int K, int c0, int N, bool strip) {
+        CholUpdArgs g;                                // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
+        g.P = A + (size_t)c0 * lda + p0; g.C = A + (size_t)c0 * lda + c0; g.N = N; g.K = K; g.lda = lda;
+        g.strideA = strideA; g.active = active; g.listed = listed ? 1 : 0; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = c0;
+        g.R = rhs; g.strideR = stride_rhs; g.k0g = p0; g.r0g = c0;
+        g.Csrc = nullptr; g.strideSrc = 0; g.lamv = nullptr; g.lam = 0.0; g.strip = strip ? 1 : 0;
+        if (from && p0 == 0) { g.Csrc = from->H + (size_t)c0 * lda + c0; g.strideSrc = from->stride; g.lamv = from->lamv; g.lam = from->lam; }
+        const int T = (N + CB - 1) / CB, TC = (N + extra + CB - 1) / CB;
+        const int tiles = strip ? TC : T * (T + 1) / 2 + (TC > T ? T : 0);
+        hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, batch), dim3(256), 0, s, g);
+    };
+    for (int j0 = 0; j0 < n;) {
         const int jb = (n - j0) < CB ? (n - j0) : CB;
         if (!factored) hipLaunchKernelGGL(potf2_upper_kernel, dim3(1, batch), dim3(256), 0, s, A, lda, j0, jb, info, strideA, active, listed ? 1 : 0, dinv, (size_t)1024);
         const int rest = n - j0 - jb;
         if (rest + extra <= 0) break;
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, listed ? 1 : 0, dinv, (size_t)1024,
-                           rhs, stride_rhs);
+        launch_trsm(j0, rest);
         VSLAM_HIP_TRY(ctx, hipGetLastError());
         if (rest <= 0) break;
-        CholUpdArgs g;                                // A[rest, rest] -= X^T X (upper triangle; the rest is zeroed at the end)
-        g.P = A + (size_t)(j0 + jb) * lda + j0; g.C = A + (size_t)(j0 + jb) * lda + j0 + jb; g.N = rest; g.K = jb; g.lda = lda;
-        g.strideA = strideA; g.active = active; g.listed = listed ? 1 : 0; g.dinv = dinv; g.stride_dinv = 1024; g.info = info; g.j0 = j0 + jb;
-        g.R = rhs; g.strideR = stride_rhs; g.k0g = j0; g.r0g = j0 + jb;
-        g.Csrc = nullptr; g.strideSrc = 0; g.lamv = nullptr; g.lam = 0.0;
-        if (from && j0 == 0) { g.Csrc = from->H + (size_t)jb * lda + jb; g.strideSrc = from->stride; g.lamv = from->lamv; g.lam = from->lam; }
-        const int T = (rest + CB - 1) / CB, TC = (rest + extra + CB - 1) / CB;
-        hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2 + (TC > T ? T : 0), batch), dim3(256), 0, s, g);
-        VSLAM_HIP_TRY(ctx, hipGetLastError());
         factored = true;                              // the update's workgroup for the next diagonal tile factors it as well
+        if (two_level && rest > CB) {
+            launch_update(j0, CB, j0 + CB, rest, true);                       // block row j0 + 64 .. j0 + 127, and its diagonal block factored
+            launch_trsm(j0 + CB, rest - CB);
+            launch_update(j0, 2 * CB, j0 + 2 * CB, rest - CB, false);         // everything beyond, both block rows at once
+            VSLAM_HIP_TRY(ctx, hipGetLastError());
+            j0 += 2 * CB;
+            continue;
+        }
+        launch_update(j0, jb, j0 + jb, rest, false);
+        VSLAM_HIP_TRY(ctx, hipGetLastError());
+        j0 += CB;
     }
     if (!zero_lower) return VSLAM_OK;
     const size_t zblocks = ((size_t)n * n + 4095) / 4096;
