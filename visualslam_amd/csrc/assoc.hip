@@ -132,8 +132,8 @@ __device__ __forceinline__ double wave_sum(double v)
 // k.. (make_reflector, apply_reflector, make_reflector with the same conventions), the coupling of the two columns
 // with z_prev and v1^T v0 for the commit -- the whole serial part of a landmark without a workgroup barrier (a
 // workgroup-wide sum costs two barriers of sixteen waves for vectors a single wave holds in a few elements per lane).
-// out: beta0, tau0, r01, beta1, tau1, c0 . z, c1 . z, v1^T v0.  On return ca holds the scaled reflector tails as
-// the workgroup-wide routines leave them.
+// out: beta0, tau0, r01, beta1, tau1, c0 . z, c1 . z, v1^T v0, and the number of leading rows outside which both
+// reflectors are zero.  On return ca holds the scaled reflector tails as the workgroup-wide routines leave them.
 __device__ void wave_panel(double *ca, const double *z, int k, int N, double *out)
 {
     const int lane = threadIdx.x & 63;
@@ -159,11 +159,14 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
     const double r01 = c1[k] - d;
     // scale the tail of column 0, apply the reflector to column 1, and gather reflector 1's sums on the way
     double t1 = 0.0;
+    int last = k + 1;                                            // last row in which a reflector can be non-zero
     for (int r = k + 1 + lane; r < N; r += 64) {
         const double v = c0[r] * scale0, y = c1[r] - d * v;
         c0[r] = v; c1[r] = y;
         if (r > k + 1) t1 += y * y;
+        if (v != 0.0 || y != 0.0) last = r;
     }
+    for (int off = 32; off >= 1; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
     if (lane == 0) c1[k] = r01;
     t1 = wave_sum(t1);
     double beta1, tau1 = 0.0, scale1 = 0.0;
@@ -178,13 +181,13 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
     double ps = 0.0;                                             // v1^T v0 = v0(k+1) + sum_{r >= k+2} v0(r) v1(r)
     for (int r = k + 2 + lane; r < N; r += 64) { const double v = c1[r] * scale1; c1[r] = v; ps += c0[r] * v; }
     ps = wave_sum(ps) + ((k + 1 < N) ? c0[k + 1] : 0.0);
-    if (lane == 0) { out[0] = beta0; out[1] = tau0; out[2] = r01; out[3] = beta1; out[4] = tau1; out[5] = p0; out[6] = p1; out[7] = ps; }
+    if (lane == 0) { out[0] = beta0; out[1] = tau0; out[2] = r01; out[3] = beta1; out[4] = tau1; out[5] = p0; out[6] = p1; out[7] = ps; out[8] = (double)(min(last, N - 1) + 1); }
 }
 
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
-    __shared__ double pn[8];                 // results of wave_panel
+    __shared__ double pn[9];                 // results of wave_panel
     __shared__ double cand_z0[AT / 64], cand_z1[AT / 64];
     __shared__ double cand_v[AT / 64];
     __shared__ int cand_i[AT / 64];
@@ -220,11 +223,12 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         __syncthreads();
         // ---- two new reflectors on rows k.. (joint factor) ----
         double tau0, tau1, beta0, beta1, r01, c0, c1, s01 = 0.0;
+        int rmax = N;                        // rows k .. rmax - 1 are all the new reflectors touch
         if (a.vec_lds) {
             // the vectors live in LDS: one wave does the serial part, everybody else meets it at one barrier
             if (wave == 0) wave_panel(ca, z, k, N, pn);
             __syncthreads();
-            beta0 = pn[0]; tau0 = pn[1]; r01 = pn[2]; beta1 = pn[3]; tau1 = pn[4]; c0 = pn[5]; c1 = pn[6]; s01 = pn[7];
+            beta0 = pn[0]; tau0 = pn[1]; r01 = pn[2]; beta1 = pn[3]; tau1 = pn[4]; c0 = pn[5]; c1 = pn[6]; s01 = pn[7]; rmax = (int)pn[8];
         } else {
             beta0 = make_reflector(ca, k, N, red, &tau0);
             apply_reflector(ca, tau0, k, N, ca + N, red);
@@ -301,8 +305,11 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         if (best_i < 0) { __syncthreads(); continue; }
         // ---- commit: the two reflectors go into every later landmark's columns; z and the running sums grow by two.
         // v0 = [1 at k; ca(k+1..)], v1 = [1 at k+1; ca(N + k+2..)].  With s01 = v1^T v0 both act in one read pass
-        // and one update pass per column:  a -= tau0 d0 v0 + tau1 (e1 - tau0 d0 s01) v1,  d0 = v0^T a, e1 = v1^T a. ----
-        {
+        // and one update pass per column:  a -= tau0 d0 v0 + tau1 (e1 - tau0 d0 s01) v1,  d0 = v0^T a, e1 = v1^T a.
+        // A factor that arrives upper triangular (what affineTransform returns) keeps the work small: while no landmark
+        // has been left out both reflectors are the identity (tau = 0: nothing to apply), and after s omissions they are
+        // zero below row 2 j + 1, so the passes stop there. ----
+        if (tau0 != 0.0 || tau1 != 0.0) {
             if (!a.vec_lds) {
                 double ps = (tid == 0 && k + 1 < N) ? ca[k + 1] : 0.0;                   // v1(k+1) = 1 times v0(k+1)
                 for (int r = k + 2 + tid; r < N; r += AT) ps += ca[r] * ca[N + r];
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
                 double d0[CG], e1[CG];
 #pragma unroll
                 for (int q = 0; q < CG; ++q) { d0[q] = 0.0; e1[q] = 0.0; }
-                for (int r = k + lane; r < N; r += 64) {
+                for (int r = k + lane; r < rmax; r += 64) {
                     const double v0 = (r == k) ? 1.0 : ca[r];
                     const double v1 = (r == k) ? 0.0 : ((r == k + 1) ? 1.0 : ca[N + r]);
                     double av[CG];
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
                     d0[q] *= tau0;
                     e1[q] = tau1 * (e1[q] - d0[q] * s01);
                 }
-                for (int r = k + lane; r < N; r += 64) {
+                for (int r = k + lane; r < rmax; r += 64) {
                     const double v0 = (r == k) ? 1.0 : ca[r];
                     const double v1 = (r == k) ? 0.0 : ((r == k + 1) ? 1.0 : ca[N + r]);
                     double av[CG];
