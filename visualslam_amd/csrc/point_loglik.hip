@@ -326,7 +326,8 @@ __device__ __forceinline__ bool assemble_special(int col, int row, int n)
     return row >= d0 && row < d0 + 3;
 }
 
-__global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
+constexpr int kAsmThreads = 256;        // 512 and 1 024 threads with slices of 32-128 KB measured 172-233 us against 155-160
+__global__ __launch_bounds__(kAsmThreads) void loglik_assemble_kernel(TermsArgs t)
 {
     extern __shared__ double srec[];                   // records of the landmarks whose columns this slice touches
     const LoglikArgs &a = t.a;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         // of its own landmark (N[.][i]).  They are staged per column, in row order, so that an element finds its value
         // with two comparisons and one LDS read and no wavefront takes a slow path for the sake of a few lanes.
         double *scol = srec;                                                    // [column of the slice][9]
-        for (int q = tid; q < (cB - cA + 1) * 9; q += kThreads) {
+        for (int q = tid; q < (cB - cA + 1) * 9; q += kAsmThreads) {
             const int cl = q / 9, f = q - 9 * cl, col = cA + cl, j = (col - 12) / 3, i = col - 12 - 3 * j;
             scol[q] = f < 3 ? -rec_N(rec, L, j, f, i) : (f < 6 ? rec[(size_t)(6 + i * 3 + (f - 3)) * L + j] : rec_N(rec, L, j, f - 6, i));
         }
@@ -379,14 +380,14 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         const uint32_t npair = (e1 - e) >> 1;
         const uint32_t idx = e + 2u * (uint32_t)tid;
         int col = (int)(idx / n), row = (int)(idx - (uint32_t)col * n);
-        for (uint32_t k = tid; k < npair; k += kThreads) {
+        for (uint32_t k = tid; k < npair; k += kAsmThreads) {
             const double *cv = scol + (col - cA) * 9;
             const int d0 = 3 * (int)(((unsigned)col * 43691u) >> 17);           // 3 * (col / 3) for col < 65536
             double2 o;
             o.x = in_column(cv, d0, row);
             o.y = row + 1 == n ? 0.0 : in_column(cv, d0, row + 1);              // a pair that ends in row 0 of the next column: zero there
             *reinterpret_cast<double2 *>(H + e + 2 * k) = o;
-            row += 2 * kThreads;
+            row += 2 * kAsmThreads;
             while (row >= n) { row -= n; ++col; }
         }
         if (((e1 - e) & 1) && tid == 0) {              // tail single (only at the instance end)
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
         if (cB >= 12) {
             j_lo = cA >= 12 ? (cA - 12) / 3 : 0;
             const int j_hi = (cB - 12) / 3;
-            for (int q = tid; q < (j_hi - j_lo + 1) * kRecFields; q += kThreads) {
+            for (int q = tid; q < (j_hi - j_lo + 1) * kRecFields; q += kAsmThreads) {
                 const int jl = q / kRecFields, f = q - jl * kRecFields;
                 srec[q] = rec[(size_t)f * L + j_lo + jl];
             }
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
     const uint32_t npair = (e1 - e) >> 1;
     const uint32_t idx = e + 2u * (uint32_t)tid;
     int col = (int)(idx / n), row = (int)(idx - (uint32_t)col * n);
-    for (uint32_t k = tid; k < npair; k += kThreads) {
+    for (uint32_t k = tid; k < npair; k += kAsmThreads) {
         int col2 = col, row2 = row + 1;
         if (row2 == n) { row2 = 0; ++col2; }
         double2 o = make_double2(0.0, 0.0);
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(kThreads) void loglik_assemble_kernel(TermsArgs t)
             o.y = assemble_value(t, rec, part_b, srec, j_lo, col2, row2);
         }
         *reinterpret_cast<double2 *>(H + e + 2 * k) = o;
-        row += 2 * kThreads;
+        row += 2 * kAsmThreads;
         while (row >= n) { row -= n; ++col; }
     }
     if (((e1 - e) & 1) && tid == 0) {                  // tail single (only at the instance end)
@@ -526,7 +527,7 @@ static vslam_status launch_point_loglik_impl(vslam_ctx *ctx, const CamK &cam, in
         const size_t lds_rec = (size_t)((slice_bytes / 8) / (3 * n) + 3) * kRecFields, lds_col = (size_t)((slice_bytes / 8) / n + 2) * 9;
         const size_t lds = (lds_rec > lds_col ? lds_rec : lds_col) * sizeof(double);
 
-        hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), block, lds, ctx->stream, t);
+        hipLaunchKernelGGL(loglik_assemble_kernel, dim3(slices, batch), dim3(kAsmThreads), lds, ctx->stream, t);
         if (timed) { VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->tev[2], ctx->stream)); ctx->tev_recorded = true; }
     } else if (H) {
         dim3 grid(1 + panels, batch);
