@@ -103,6 +103,37 @@ def test_affine_bundle_bank_vs_oracle(ctx, gcam, ocam, layout):
         assert not np.tril(Syy[b].T, -1).any()
 
 
+def test_affine_bundle_large_bank_and_tall_single_vs_oracle(ctx, gcam, ocam):
+    """The two forms of the QR that stop at the band under which the stacked diagonal noise factor leaves zeros: a bank of
+    more than eight filters (one workgroup per matrix, panels of band + 32 rows) and one tall transform (blocks of 128
+    columns resident in LDS, band + 128 rows per launch), each against the dense formula of the oracle."""
+    import torch
+    from oracle import pyoracle as orc
+    from visualslam_amd import api, synthetic as syn
+    B, L = 12, 150
+    n, m = 12 + 3 * L, 2 * L
+    scs = [syn.Scene(L, 700 + b) for b in range(3)]
+    xs = np.stack([scs[b % 3].x for b in range(B)])
+    dev = torch.device("cuda:0")
+    dx = torch.tensor(xs, device=dev)
+    dS = torch.tensor(np.stack([np.ascontiguousarray(scs[b % 3].S.T) for b in range(B)]), device=dev)
+    dmu = torch.full((B, m), float("nan"), dtype=torch.float64, device=dev)
+    dSy = torch.full((B, m, m), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    api.affine_bundle_batch_dev(ctx, gcam, dx, dS, dmu, dSy, None, 0)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    Syy = dSy.cpu().numpy()
+    for b in (0, 1, 2, 11):
+        h0, SR0, C0, _ = orc.bundle_measure(xs[b], ocam, 0)
+        assert rel_err(Syy[b].T, orc.affine_sqrt(scs[b % 3].S, C0, SR0)) <= TOL
+        assert not np.tril(Syy[b].T, -1).any()
+    sc = syn.Scene(400, 5)                                     # 2012 x 800: six resident blocks and a tail of panels
+    muy, Syy1, _ = api.affine_bundle(ctx, gcam, sc.x, sc.S, 0)
+    h0, SR0, C0, _ = orc.bundle_measure(sc.x, ocam, 0)
+    assert rel_err(muy, h0) <= TOL and rel_err(Syy1, orc.affine_sqrt(sc.S, C0, SR0)) <= TOL
+
+
 def test_condition_on_marginal(ctx):
     from oracle import pyoracle as orc
     from visualslam_amd import api

@@ -283,7 +283,7 @@ extern "C" vslam_status vslam_affine_bundle(vslam_ctx *ctx, const vslam_camera *
     hipLaunchKernelGGL(bundle_jac_compact_kernel, dim3((L + 63) / 64), dim3(64), 0, s, k, dx, L, layout, dh, dc, rec);
     hipLaunchKernelGGL(s_times_ct_kernel, dim3((rows + 255) / 256, L), dim3(256), 0, s, dS, n, n, rec, L, layout, dA, rows);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, 0, 1, qws));
+    VSLAM_TRY(qr_upper_dev(ctx, dA, rows, m, rows, 0, 1, qws, n));      // the noise rows are diagonal: column c is zero below row n + c
     VSLAM_TRY(d2h(ctx, muy, dh, m * 8));
     if (code) VSLAM_TRY(d2h(ctx, code, dc, L * 4));
     VSLAM_TRY(d2h_2d(ctx, Syy, (size_t)ldSyy * 8, dA, (size_t)rows * 8, (size_t)m * 8, m));

@@ -921,7 +921,10 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
 {
     vslam_ctx *ctx = q.ctx;
     hipStream_t s = ctx->stream, t = ctx->side;
-    const int ob = q.pl.bw, mp0 = q.rows - j0, par = blk & 1;
+    // rows of a block from its diagonal origin on: all of them, or as far as the band lets its last column reach
+    const int ob = q.pl.bw, par = blk & 1;
+    auto block_rows = [&](int j) { const int mp = q.rows - j; return (q.band >= 0 && q.band + ob < mp) ? q.band + ob : mp; };
+    const int mp0 = block_rows(j0), mpp = blk > 0 ? block_rows(j0 - ob) : 0;       // this block's rows, the previous block's
     if (blk >= 2) VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev[4 + par], 0));
     const unsigned seq0 = 256u * q.launches++;
     if (blk == 0)
@@ -930,7 +933,7 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
     else
         VSLAM_TRY(qr_block_launch(ctx, s, q.pl, q.A + (size_t)j0 * q.lda + (j0 - ob), q.lda, q.strideA, 1, mp0 + ob, ob, ob, seq0,
                                   q.w.Mo[par], 0, q.w.Vbuf[par], mp0, q.w.xbuf,
-                                  ob, q.w.Vbuf[par ^ 1], mp0 + ob, q.w.Mo[par ^ 1], ob / QR_NB));
+                                  ob, q.w.Vbuf[par ^ 1], mpp, q.w.Mo[par ^ 1], ob / QR_NB, mpp));
     const int first = next_resident ? j0 + 2 * ob : j0 + ob;     // first column the side stream updates
     const int nside = q.cols - first;
     if (nside <= 0) return VSLAM_OK;
@@ -958,7 +961,8 @@ static vslam_status qr_outer_block_resident(QrJob &q, int j0, int blk, bool next
 static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int cols, int lda, size_t strideA, int batch, void *ws,
                                        int band, bool zero_lower);
 
-// The band is used by the panel-by-panel form only (banks, short matrices): the tallest panel then has band + NB rows.
+// Rows of the tallest launch: with a band a panel has band + NB rows; the form that keeps 128-column blocks resident plans
+// for the whole height (its launches then simply use fewer workgroups than planned).
 static int tallest_panel(int rows, int cols, int batch, int band)
 {
     if (band < 0 || use_outer_blocks(rows, cols, batch) || getenv("VSLAM_QR_NO_BAND")) return rows;
@@ -988,7 +992,7 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
     q.tbase = 0; q.rows_per = coop_rows_per(rows, batch);
     q.launches = 0; q.ob = OB;
     const int tall = tallest_panel(rows, cols, batch, band);
-    q.band = tall < rows ? band : -1;
+    q.band = (band >= 0 && band < rows && !getenv("VSLAM_QR_NO_BAND")) ? band : -1;
     q.use_block = qr_block_plan(tall, batch, block_width(rows, cols, batch), &q.pl) && !getenv("VSLAM_QR_COLUMNWISE");
     qr_carve(ws, rows, cols, batch, &q.w);
     const int kmax = rows < cols ? rows : cols;
@@ -1011,6 +1015,7 @@ static vslam_status qr_upper_dev_inner(vslam_ctx *ctx, double *A, int rows, int 
         VSLAM_TRY(side_stream_init(ctx));
         int blk = 0;
         const bool resident = q.use_block && q.pl.bw > QR_NB && !getenv("VSLAM_QR_PANELWISE");
+        if (!resident) q.band = -1;                  // the panel-wise outer blocks keep whole columns of reflectors: no band there
         if (resident) {
             q.ob = q.pl.bw;
             for (; j0 + q.ob <= kmax; j0 += q.ob, ++blk)

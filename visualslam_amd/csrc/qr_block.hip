@@ -71,6 +71,7 @@ struct QbArgs {
     int roff;                                // rows of this launch above the block's diagonal origin (they belong to the previous block)
     const double *Vprev; int ldvp;           // roff > 0: explicit reflectors of the previous block, element (first row of this launch, its column 0)
     const double *Tprev; int prev_np;        //           and its panels' T (QR_MSTRIDE apart); applied to the resident columns first
+    int vprev_rows;                          //           rows of Vprev counted from the launch's first row (zero beyond: a banded matrix)
     double *xbuf; size_t xstride;            // exchange area per matrix: part [G][cmax], red [cmax], top [1024]
     int cmax;
     int *err;
@@ -646,9 +647,9 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int i = k0 + 4 * u + kr;
-                            const bool in = i < nr;
-                            xv[u][0] = in ? Vp[(size_t)l15 * a.ldvp + i] : 0.0;
-                            xv[u][1] = in ? Vp[(size_t)(16 + l15) * a.ldvp + i] : 0.0;
+                            const bool in = i < nr, inv = in && r0 + i < a.vprev_rows;
+                            xv[u][0] = inv ? Vp[(size_t)l15 * a.ldvp + i] : 0.0;
+                            xv[u][1] = inv ? Vp[(size_t)(16 + l15) * a.ldvp + i] : 0.0;
                             zv[u] = (in && zc0 + l15 < a.bwc) ? Bk[(size_t)(zc0 + l15) * ldr + i] : 0.0;
                         }
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[0][0], zv[0], acc0, 0, 0, 0);
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(QB_T) void qr_block_kernel(QbArgs a)
                     const int i = 16 * rt + l15;
                     double vq[8];
 #pragma unroll
-                    for (int q8 = 0; q8 < 8; ++q8) vq[q8] = (i < nr) ? Vp[(size_t)(4 * q8 + kr) * a.ldvp + i] : 0.0;
+                    for (int q8 = 0; q8 < 8; ++q8) vq[q8] = (i < nr && r0 + i < a.vprev_rows) ? Vp[(size_t)(4 * q8 + kr) * a.ldvp + i] : 0.0;
                     double4_t u[2][2];
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) { u[cb][0] = (double4_t){0.0, 0.0, 0.0, 0.0}; u[cb][1] = u[cb][0]; }
@@ -1004,7 +1005,7 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p)
 
 vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPlan &pl, double *A, int lda, size_t strideA, int batch,
                              int mp, int bwc, int nfac, unsigned seq0, double *T, size_t strideT, double *V, int ldv,
-                             double *xbuf, int roff, const double *Vprev, int ldvp, const double *Tprev, int prev_np)
+                             double *xbuf, int roff, const double *Vprev, int ldvp, const double *Tprev, int prev_np, int vprev_rows)
 {
     if (bwc > pl.bw || nfac > bwc || nfac > mp || nfac < 1) return fail(ctx, VSLAM_ERR_SHAPE, "qr block: %d columns (%d to factor) in a block of %d", bwc, nfac, pl.bw);
     const int G = (mp + pl.rows_per - 1) / pl.rows_per;
@@ -1033,7 +1034,7 @@ vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPl
         a.A = A + (size_t)b0 * strideA; a.lda = lda; a.strideA = strideA; a.mp = mp; a.bwc = bwc; a.nfac = nfac;
         a.rows_per = pl.rows_per; a.G = G; a.ldr = pl.ldr; a.bw = pl.bw; a.seq0 = seq0;
         a.T = T + (size_t)b0 * strideT; a.strideT = strideT; a.V = V; a.ldv = ldv;
-        a.roff = roff; a.Vprev = Vprev; a.ldvp = ldvp; a.Tprev = Tprev; a.prev_np = prev_np;
+        a.roff = roff; a.Vprev = Vprev; a.ldvp = ldvp; a.Tprev = Tprev; a.prev_np = prev_np; a.vprev_rows = vprev_rows < 0 ? mp : vprev_rows;
         a.xbuf = xbuf + (size_t)b0 * pl.xbuf_doubles; a.xstride = pl.xbuf_doubles;
         a.cmax = pl.cmax;
         a.err = ctx->flags;

@@ -27,10 +27,11 @@ bool qr_block_plan(int rows, int batch, int bw_want, QrBlockPlan *p);
 // resident and updated.  seq0: sequence numbers seq0+1 ... seq0+64*panels are used (they must grow from launch to
 // launch of one factorisation).  T receives one compact-WY factor per panel; V (optional, batch 1) the explicit
 // reflectors.  roff > 0: the launch starts roff rows above the block's diagonal origin (A, mp and Vprev count from
-// there) and first applies the previous block's reflectors Vprev / Tprev (prev_np panels) to the resident columns.
+// there) and first applies the previous block's reflectors Vprev / Tprev (prev_np panels) to the resident columns;
+// vprev_rows >= 0: Vprev has that many rows (a banded matrix: the rest of the launch's rows see zeros).
 vslam_status qr_block_launch(vslam_ctx *ctx, hipStream_t stream, const QrBlockPlan &pl, double *A, int lda, size_t strideA, int batch,
                              int mp, int bwc, int nfac, unsigned seq0, double *T, size_t strideT, double *V, int ldv,
                              double *xbuf, int roff = 0, const double *Vprev = nullptr, int ldvp = 0,
-                             const double *Tprev = nullptr, int prev_np = 0);
+                             const double *Tprev = nullptr, int prev_np = 0, int vprev_rows = -1);
 
 }  // namespace vslam
