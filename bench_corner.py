@@ -10,6 +10,26 @@ W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0
 
 
+def issue_roofline(counter_file, kernel_part, step_ms, launches_per_step=1):
+    """The front-end kernels are bound by instruction issue, not by HBM: a wave64 VALU instruction occupies one of the
+    1 024 SIMDs (256 compute units x 4) for four cycles.  From the committed SQ counter pass (SQ_INSTS_VALU, mean per
+    launch) this gives the time the kernel's instruction stream needs at best, to set beside the measured step."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", counter_file)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        per_kernel = json.load(fh).get("mean_per_launch", {})
+    hit = [v for k, v in per_kernel.items() if kernel_part in k and "SQ_INSTS_VALU" in v]
+    if not hit:
+        return None
+    insts = float(hit[0]["SQ_INSTS_VALU"]) * launches_per_step
+    simds, cycles_per_inst, clock_hz = 1024, 4, 2.4e9
+    bound_ms = insts * cycles_per_inst / simds / clock_hz * 1e3
+    return {"bound": "valu issue", "kernel": kernel_part, "wave_instructions_per_step": insts, "peak": "1024 SIMDs x 1 instruction / 4 cycles at 2.4 GHz",
+            "issue_time_ms": bound_ms, "step_ms": step_ms, "frac": bound_ms / step_ms,
+            "source": "SQ_INSTS_VALU replayed from profiles/%s (rocprofv3 --pmc pass); frac = issue time / measured step (sort, merge and emit kernels included in the step)" % counter_file}
+
+
 def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
     import torch
     import torch.distributed as dist
@@ -84,6 +104,8 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
         "dtype": "u8 -> int32 structure tensor -> f32 response",
         "keypoints_gathered_to_root": kp_msg,
     }
+    if F == 64:
+        res["issue_roofline"] = issue_roofline("r03_corner_sq_counters.json", "corner_strip_kernel", dev_ms)
     # FAST-9/16 (first stage of cv::ORB::detect) on the same frames: threshold 20 as the reference configures it
     fout = torch.zeros((F, cap, 3), dtype=torch.int32, device=dev)
     fcnt = torch.zeros(F, dtype=torch.int32, device=dev)
@@ -111,6 +133,8 @@ def run_corner_leg(args, ctx, dev, stream, rank, world, barrier):
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": falg / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ftraffic,
                                  "traffic_source": "replayed from profiles/traffic_fast9.json (rocprofv3 --pmc passes of tools/run_fast9.py 64); not re-measured in this run",
                                  "algorithmic_bytes_per_step": falg}}
+    if F == 64:
+        res["fast9"]["issue_roofline"] = issue_roofline("r03_fast9_sq_counters.json", "fast9_tile_kernel", fast_ms)
     # ORB as the reference configures it: level-0 keypoints (FAST -> edge -> 2n by FAST score -> Harris at the corners
     # -> n best) for all frames in one call, then blur + orientation + descriptors frame by frame; and the whole
     # 8-level pyramid of one host frame through the host-pointer entry (PCIe and the level loop included)
