@@ -1027,13 +1027,81 @@ __global__ __launch_bounds__(256) void resize_bilinear4_kernel(const uint8_t *sr
     else for (int i = 0; i < 4 && x + i < dw; ++i) d[i] = (uint8_t)(o >> (8 * i));
 }
 
+// The same for sources whose rows start on 4-byte boundaries and shrink factors up to 2: the four output pixels of a
+// thread take their source pixels from at most 11 adjacent columns, which arrive as three aligned words per source row
+// (six loads instead of sixteen byte reads -- the byte form is bound by the number of memory instructions, not by their
+// bytes or by arithmetic), and every division is a 32-bit one: the block's first numerator is uniform, a thread's is
+// k = 4 * threadIdx.x steps of (qs, rs) further on, and rb + k * rs stays below 2^31.
+__global__ __launch_bounds__(256) void resize_bilinear4w_kernel(const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw,
+                                                                int dh, int dstride, size_t dframe, int qs, int rs, int word_stores)
+{
+    const int xb = 1024 * blockIdx.x, k = 4 * threadIdx.x, x = xb + k, y = blockIdx.y;
+    if (x >= dw) return;
+    src += (size_t)blockIdx.z * sframe;
+    dst += (size_t)blockIdx.z * dframe;
+    long long Y = ((long long)(2 * y + 1) * sh * 1024) / dh - 1024;
+    Y = Y < 0 ? 0 : (Y > (long long)(sh - 1) * 2048 ? (long long)(sh - 1) * 2048 : Y);
+    const int y0 = (int)(Y >> 11), ay = (int)(Y & 2047), y1 = min(y0 + 1, sh - 1);
+    const uint8_t *r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
+    const long long Nb = (long long)(2 * xb + 1) * sw * 1024;              // uniform over the workgroup
+    const long long qb = Nb / dw;
+    const unsigned rb = (unsigned)(Nb - qb * dw);
+    const unsigned rk = rb + (unsigned)k * (unsigned)rs, carry = rk / (unsigned)dw;
+    int q = (int)qb + k * qs + (int)carry, r = (int)(rk - carry * (unsigned)dw);
+    const int xmax = (sw - 1) * 2048;
+    int X[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        X[i] = min(max(q - 1024, 0), xmax);
+        q += qs; r += rs;
+        if (r >= dw) { r -= dw; ++q; }
+    }
+    const int xa = (X[0] >> 11) & ~3;
+    uint32_t o = 0;
+    if (xa + 12 <= sstride && (X[3] >> 11) + 1 - xa <= 11) {
+        const uint32_t *w0p = reinterpret_cast<const uint32_t *>(r0 + xa), *w1p = reinterpret_cast<const uint32_t *>(r1 + xa);
+        const uint32_t a0 = w0p[0], a1 = w0p[1], a2 = w0p[2], b0 = w1p[0], b1 = w1p[1], b2 = w1p[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x0 = X[i] >> 11, ax = X[i] & 2047, off = x0 - xa;
+            const uint32_t alo = off < 4 ? a0 : (off < 8 ? a1 : a2), ahi = off < 4 ? a1 : (off < 8 ? a2 : 0u);
+            const uint32_t blo = off < 4 ? b0 : (off < 8 ? b1 : b2), bhi = off < 4 ? b1 : (off < 8 ? b2 : 0u);
+            const uint32_t pa = __builtin_amdgcn_alignbyte(ahi, alo, off & 3), pb = __builtin_amdgcn_alignbyte(bhi, blo, off & 3);
+            const bool last = x0 >= sw - 1;                                  // the right neighbour is the pixel itself
+            const unsigned p00 = pa & 255u, p01 = last ? p00 : (pa >> 8) & 255u, p10 = pb & 255u, p11 = last ? p10 : (pb >> 8) & 255u;
+            // (p00 (1 - ax) + p01 ax) (1 - ay) + (p10 (1 - ax) + p11 ax) ay: the same integer as the four-term sum, fewer operations
+            const unsigned v = (p00 * (2048 - ax) + p01 * ax) * (2048 - ay) + (p10 * (2048 - ax) + p11 * ax) * ay;
+            o |= ((v + (1u << 21)) >> 22) << (8 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x0 = X[i] >> 11, ax = X[i] & 2047, x1 = min(x0 + 1, sw - 1);
+            const unsigned p00 = r0[x0], p01 = r0[x1], p10 = r1[x0], p11 = r1[x1];
+            // (p00 (1 - ax) + p01 ax) (1 - ay) + (p10 (1 - ax) + p11 ax) ay: the same integer as the four-term sum, fewer operations
+            const unsigned v = (p00 * (2048 - ax) + p01 * ax) * (2048 - ay) + (p10 * (2048 - ax) + p11 * ax) * ay;
+            o |= ((v + (1u << 21)) >> 22) << (8 * i);
+        }
+    }
+    uint8_t *d = dst + (size_t)y * dstride + x;
+    if (word_stores && x + 4 <= dw) *reinterpret_cast<uint32_t *>(d) = o;
+    else for (int i = 0; i < 4 && x + i < dw; ++i) d[i] = (uint8_t)(o >> (8 * i));
+}
+
 static vslam_status launch_resize(vslam_ctx *ctx, const uint8_t *src, int sw, int sh, int sstride, size_t sframe, uint8_t *dst, int dw, int dh,
                                   int dstride, size_t dframe, int frames)
 {
     const long long step = 2ll * sw * 1024;                  // numerator step of the source position per output pixel
     const int words = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dstride | (uintptr_t)dframe) & 3) == 0;
-    hipLaunchKernelGGL(resize_bilinear4_kernel, dim3((dw + 1023) / 1024, dh, frames), dim3(256), 0, ctx->stream, src, sw, sh, sstride, sframe, dst, dw, dh,
-                       dstride, dframe, (int)(step / dw), (int)(step % dw), words);
+    const bool src_words = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)sstride | (uintptr_t)sframe) & 3) == 0;
+    // word loads need 32-bit positions: (sw - 1) * 2048 and the carried remainders (1 020 * rs + dw) must fit
+    const bool small = sw <= 65536 && dw <= 65536 && step / dw < (1ll << 20);
+    if (src_words && small && !getenv("VSLAM_RESIZE_BYTES"))
+        hipLaunchKernelGGL(resize_bilinear4w_kernel, dim3((dw + 1023) / 1024, dh, frames), dim3(256), 0, ctx->stream, src, sw, sh, sstride, sframe, dst, dw, dh,
+                           dstride, dframe, (int)(step / dw), (int)(step % dw), words);
+    else
+        hipLaunchKernelGGL(resize_bilinear4_kernel, dim3((dw + 1023) / 1024, dh, frames), dim3(256), 0, ctx->stream, src, sw, sh, sstride, sframe, dst, dw, dh,
+                           dstride, dframe, (int)(step / dw), (int)(step % dw), words);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
