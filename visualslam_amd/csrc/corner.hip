@@ -1601,13 +1601,15 @@ struct OrbPackArgs {
     int32_t *count, *level_counts;                        // [frames], optional [frames][nlevels_out]
 };
 
-// One workgroup per frame: the levels' keypoint lists one after the other (level 0 first), positions scaled to the
-// base image as cv::ORB reports them (pt *= scale, in float).  A level that overflowed, or more keypoints than `cap`,
-// gives count -1 for the frame.
+// The levels' keypoint lists of a frame one after the other (level 0 first), positions scaled to the base image as
+// cv::ORB reports them (pt *= scale, in float).  A level that overflowed, or more keypoints than `cap`, gives count -1
+// for the frame.  Grid (frame, level, part): every workgroup works out the frame's offsets for itself and copies one
+// part of one level (a workgroup per frame left three quarters of the chip idle).
+constexpr int ORB_PACK_PARTS = 4;
 __global__ __launch_bounds__(256) void orb_pack_kernel(OrbPackArgs a)
 {
     __shared__ int off[VSLAM_ORB_MAX_LEVELS + 1];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x, lv = blockIdx.y, part = blockIdx.z, tid = threadIdx.x;
     if (tid == 0) {
         int total = 0;
         bool bad = false;
@@ -1618,18 +1620,22 @@ __global__ __launch_bounds__(256) void orb_pack_kernel(OrbPackArgs a)
         }
         off[a.nl] = total;
         if (total > a.cap) bad = true;
-        a.count[f] = bad ? -1 : total;
-        if (a.level_counts)
-            for (int l = 0; l < a.nlevels_out; ++l) a.level_counts[(size_t)f * a.nlevels_out + l] = l < a.nl ? a.level_count[(size_t)l * a.frames + f] : 0;
+        if (lv == 0 && part == 0) {
+            a.count[f] = bad ? -1 : total;
+            if (a.level_counts)
+                for (int l = 0; l < a.nlevels_out; ++l) a.level_counts[(size_t)f * a.nlevels_out + l] = l < a.nl ? a.level_count[(size_t)l * a.frames + f] : 0;
+        }
         if (bad) off[a.nl] = -1;
     }
     __syncthreads();
-    if (off[a.nl] < 0) return;
-    for (int l = 0; l < a.nl; ++l) {
+    if (off[a.nl] < 0 || lv >= a.nl) return;
+    {
+        const int l = lv;
         const int k = off[l + 1] - off[l];
+        const int per = (k + ORB_PACK_PARTS - 1) / ORB_PACK_PARTS, i0 = part * per, i1 = min(k, i0 + per);
         const vslam_feature *src = a.feat[l] + (size_t)f * a.cap_l[l];
         vslam_orb_keypoint *dst = a.out + (size_t)f * a.cap + off[l];
-        for (int i = tid; i < k; i += 256) {
+        for (int i = i0 + tid; i < i1; i += 256) {
             vslam_orb_keypoint kp;
             kp.x = l == 0 ? (float)src[i].x : __fmul_rn((float)src[i].x, a.scale[l]);
             kp.y = l == 0 ? (float)src[i].y : __fmul_rn((float)src[i].y, a.scale[l]);
@@ -1639,10 +1645,10 @@ __global__ __launch_bounds__(256) void orb_pack_kernel(OrbPackArgs a)
         if (a.out_desc) {
             const float *sa = a.angle[l] + (size_t)f * a.cap_l[l];
             float *da = a.out_angle + (size_t)f * a.cap + off[l];
-            for (int i = tid; i < k; i += 256) da[i] = sa[i];
+            for (int i = i0 + tid; i < i1; i += 256) da[i] = sa[i];
             const uint32_t *sd = reinterpret_cast<const uint32_t *>(a.desc[l] + (size_t)f * a.cap_l[l] * 32);
             uint32_t *dd = reinterpret_cast<uint32_t *>(a.out_desc + ((size_t)f * a.cap + off[l]) * 32);
-            for (int i = tid; i < 8 * k; i += 256) dd[i] = sd[i];
+            for (int i = 8 * i0 + tid; i < 8 * i1; i += 256) dd[i] = sd[i];
         }
     }
 }
@@ -1729,7 +1735,7 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
     }
     pa.level_count = dcount; pa.nl = nl; pa.nlevels_out = p->nlevels; pa.frames = frames; pa.cap = cap;
     pa.out = out; pa.out_angle = angle; pa.out_desc = desc; pa.count = count; pa.level_counts = level_counts;
-    hipLaunchKernelGGL(orb_pack_kernel, dim3(frames), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(orb_pack_kernel, dim3(frames, pa.nl > 0 ? pa.nl : 1, ORB_PACK_PARTS), dim3(256), 0, s, pa);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
 }
