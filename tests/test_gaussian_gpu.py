@@ -333,3 +333,47 @@ def test_trs_driver_vs_dense_numpy_solve_on_the_gpu_box(case):
     lib.vslam_debug_trs.restype = C.c_int
     lib.vslam_debug_trs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
     H.test_trs_host_vs_dense_numpy_solve(lib, case, 162)
+
+
+def test_structural_shortcuts_change_nothing_beyond_rounding(ctx, gcam, monkeypatch):
+    """The forms that skip work on known zeros -- QR panels that stop at the band of the stacked noise factor, the bank's
+    Cholesky that updates the trailing matrix two block rows at a time -- against the forms that do not (the library's
+    switches are read at every call): the predicted measurement densities and the updated filters of a bank agree to
+    rounding."""
+    import torch
+    from visualslam_amd import api, synthetic as syn
+    B, L = 20, 60
+    n, m = 12 + 3 * L, 2 * L
+    scs = [syn.Scene(L, 900 + b, dense_S=True) for b in range(4)]
+    dev = torch.device("cuda:0")
+    dx = torch.tensor(np.stack([scs[b % 4].x for b in range(B)]), device=dev)
+    dS = torch.tensor(np.stack([np.ascontiguousarray(scs[b % 4].S.T) for b in range(B)]), device=dev)
+    dy = torch.tensor(np.stack([scs[b % 4].y for b in range(B)]), device=dev)
+    dv = torch.tensor(np.stack([scs[b % 4].visible for b in range(B)]).astype(np.uint8), device=dev)
+    torch.cuda.synchronize()
+
+    def density():
+        mu = torch.full((B, m), float("nan"), dtype=torch.float64, device=dev)
+        Sy = torch.full((B, m, m), float("nan"), dtype=torch.float64, device=dev)
+        api.affine_bundle_batch_dev(ctx, gcam, dx, dS, mu, Sy, None, 0)
+        ctx.synchronize(); torch.cuda.synchronize()
+        return Sy.cpu().numpy()
+
+    def update():
+        mup, Sp = torch.empty_like(dx), torch.empty_like(dS)
+        code, iters, status = api.measurement_update_iekf_batch_dev(ctx, gcam, dx, dS, dy, dv, 7.0, mup, Sp)
+        torch.cuda.synchronize()
+        assert not status.any()
+        return mup.cpu().numpy(), Sp.cpu().numpy(), np.asarray(iters)
+
+    Sy1 = density()
+    mu1, Sp1, it1 = update()
+    monkeypatch.setenv("VSLAM_QR_NO_BAND", "1")
+    monkeypatch.setenv("VSLAM_POTRF_ONE_LEVEL", "1")
+    Sy0 = density()
+    mu0, Sp0, it0 = update()
+    for b in range(B):
+        assert rel_err(Sy1[b], Sy0[b]) <= 1e-12
+        assert np.abs(mu1[b] - mu0[b]).max() <= 1e-9 * max(1.0, np.abs(mu0[b]).max())
+        assert rel_err(Sp1[b].T @ Sp1[b], Sp0[b].T @ Sp0[b]) <= 1e-9
+    assert np.abs(it1 - it0).max() <= 4
