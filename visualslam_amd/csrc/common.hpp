@@ -33,6 +33,10 @@ struct vslam_ctx {
     bool failed = false;         // an entry point returned an error: its staged copies are dropped, not completed
     hipStream_t side = nullptr;  // second stream for work that overlaps the main one (created on first use)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // streams on which independent chains of small kernels run beside one another (the pyramid levels of the ORB front end),
+    // with a pair of events per chain: its input is ready (main -> chain), it is done (chain -> main); created on first use
+    hipStream_t lvl_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t lvl_ev[32] = {nullptr};        // two per pyramid level (at most 16 levels)
     int *flags = nullptr;        // device: [0] set by a multi-workgroup kernel whose wait gave up
     double *chain_sol = nullptr; // device: solution blocks of the chained triangular solve as its workgroups publish them.  A ring: every call takes
                                  // a fresh stretch (filled with the not-ready pattern), the whole ring is refilled when it runs out
@@ -110,6 +114,8 @@ vslam_status h2d_upper_pipelined(vslam_ctx *ctx, double *dst_dev, size_t ldd, co
 // Looks up, once per GPU, the device address of the static scratch array of the entry point that
 // allocates nothing (point_loglik.hip); called at context creation with the device current.
 vslam_status loglik_static_scratch_init(vslam_ctx *ctx);
+// Creates ctx->lvl_stream[] and ctx->lvl_ev[] on first use.
+vslam_status level_streams_init(vslam_ctx *ctx);
 // Creates ctx->side and ctx->ev[] on first use.
 vslam_status side_stream_init(vslam_ctx *ctx);
 

@@ -1678,7 +1678,12 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
     VSLAM_TRY(ensure_lds_attr(ctx));
     // per level room for the budget plus ties at the cut
     OrbPackArgs pa;
-    size_t bytes = orb_ws_bytes(frames) + Arena::pad((size_t)VSLAM_ORB_MAX_LEVELS * frames * 4) + Arena::pad(VSLAM_ORB_PATTERN_BYTES);
+    // The levels are independent once their images exist: each level's chain of kernels (FAST, sorts, cuts, Harris, blur,
+    // descriptors -- most of them far too small to fill the chip) runs on one of three streams beside the others, each with
+    // candidate lists and a blurred image of its own, while the main stream goes on down the pyramid.
+    const bool beside = nl > 1 && frames * (size_t)w * h <= ((size_t)1 << 28) && !getenv("VSLAM_ORB_SERIAL");
+    const int nws = beside ? nl : 1;
+    size_t bytes = nws * orb_ws_bytes(frames) + Arena::pad((size_t)VSLAM_ORB_MAX_LEVELS * frames * 4) + Arena::pad(VSLAM_ORB_PATTERN_BYTES);
     int lsd[VSLAM_ORB_MAX_LEVELS];                       // row strides of the library's own level images: multiples of 16 bytes
     for (int l = 0; l < nl; ++l) lsd[l] = (lw[l] + 15) & ~15;
     const int bsd = (w + 15) & ~15;
@@ -1689,9 +1694,11 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
         if (describe) bytes += Arena::pad((size_t)frames * pa.cap_l[l] * 4) + Arena::pad((size_t)frames * pa.cap_l[l] * 32);
     }
     if (describe) bytes += Arena::pad((size_t)frames * bsd * h);
+    if (describe && beside) for (int l = 1; l < nl; ++l) bytes += Arena::pad((size_t)frames * lsd[l] * lh[l]);
     VSLAM_TRY(ws_reserve(ctx, bytes));
     Arena ar(ctx->ws);
-    void *dws = ar.take<char>(orb_ws_bytes(frames));
+    void *dws[VSLAM_ORB_MAX_LEVELS];
+    for (int l = 0; l < nws; ++l) dws[l] = ar.take<char>(orb_ws_bytes(frames));
     int32_t *dcount = ar.take<int32_t>((size_t)VSLAM_ORB_MAX_LEVELS * frames);
     int8_t *dpattern = ar.take<int8_t>(VSLAM_ORB_PATTERN_BYTES);
     uint8_t *dlev[VSLAM_ORB_MAX_LEVELS] = {nullptr};
@@ -1703,14 +1710,21 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
         dfeat[l] = ar.take<vslam_feature>((size_t)frames * pa.cap_l[l]);
         if (describe) { dangle[l] = ar.take<float>((size_t)frames * pa.cap_l[l]); ddesc[l] = ar.take<uint8_t>((size_t)frames * pa.cap_l[l] * 32); }
     }
-    uint8_t *dblur = describe ? ar.take<uint8_t>((size_t)frames * bsd * h) : nullptr;
+    uint8_t *dblur[VSLAM_ORB_MAX_LEVELS] = {nullptr};
+    if (describe) {
+        dblur[0] = ar.take<uint8_t>((size_t)frames * bsd * h);
+        for (int l = 1; l < nl; ++l) dblur[l] = beside ? ar.take<uint8_t>((size_t)frames * lsd[l] * lh[l]) : dblur[0];
+    }
     hipStream_t s = ctx->stream;
+    if (beside) VSLAM_TRY(level_streams_init(ctx));
     if (describe && !pattern) {
         int8_t own[VSLAM_ORB_PATTERN_BYTES];
         orb_default_pattern(own);
         VSLAM_TRY(h2d(ctx, dpattern, own, VSLAM_ORB_PATTERN_BYTES));
         pattern = dpattern;
     }
+    int queued = 0;                                           // chains queued on the level streams
+    vslam_status level_status = VSLAM_OK;
     for (int l = 0; l < nl; ++l) {
         const uint8_t *img = gray;
         int iw = w, ih = h, is = stride;
@@ -1720,19 +1734,34 @@ extern "C" vslam_status vslam_orb_detect_and_compute_batch_dev(vslam_ctx *ctx, c
             const int pw = l == 1 ? w : lw[l - 1], ph = l == 1 ? h : lh[l - 1], ps = l == 1 ? stride : lsd[l - 1];
             const size_t pf = l == 1 ? stride_frame : (size_t)lsd[l - 1] * lh[l - 1];
             ifr = (size_t)lsd[l] * lh[l];
-            VSLAM_TRY(launch_resize(ctx, prev, pw, ph, ps, pf, dlev[l], lw[l], lh[l], lsd[l], ifr, frames));
+            const vslam_status rs = launch_resize(ctx, prev, pw, ph, ps, pf, dlev[l], lw[l], lh[l], lsd[l], ifr, frames);
+            if (rs != VSLAM_OK) { level_status = rs; break; }
             img = dlev[l]; iw = lw[l]; ih = lh[l]; is = lsd[l];
         }
-        VSLAM_TRY(launch_orb_level(ctx, img, iw, ih, is, ifr, frames, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
-                                   dfeat[l], pa.cap_l[l], dcount + (size_t)l * frames, dws));
-        if (describe) {
-            const int bs_l = (iw + 15) & ~15;
-            VSLAM_TRY(launch_gauss7(ctx, img, iw, ih, is, ifr, dblur, bs_l, (size_t)bs_l * ih, frames));
-            VSLAM_TRY(launch_orb_describe(ctx, img, is, ifr, dblur, bs_l, (size_t)bs_l * ih, iw, ih, frames, dfeat[l], dcount + (size_t)l * frames,
-                                          pa.cap_l[l], pattern, dangle[l], ddesc[l]));
+        // the level's chain: on the main stream, or on a stream of its own behind "image ready" and in front of "level done"
+        hipStream_t chain = s;
+        if (beside) {
+            chain = ctx->lvl_stream[l % 3];
+            VSLAM_HIP_TRY(ctx, hipEventRecord(ctx->lvl_ev[2 * l], s));
+            VSLAM_HIP_TRY(ctx, hipStreamWaitEvent(chain, ctx->lvl_ev[2 * l], 0));
         }
+        ctx->stream = chain;                                  // the launchers below queue on the context's stream
+        vslam_status st = launch_orb_level(ctx, img, iw, ih, is, ifr, frames, lf[l], p->fast_threshold, p->edge_threshold, p->harris_block, p->harris_k,
+                                           dfeat[l], pa.cap_l[l], dcount + (size_t)l * frames, dws[beside ? l : 0]);
+        if (st == VSLAM_OK && describe) {
+            const int bs_l = (iw + 15) & ~15;
+            st = launch_gauss7(ctx, img, iw, ih, is, ifr, dblur[l], bs_l, (size_t)bs_l * ih, frames);
+            if (st == VSLAM_OK)
+                st = launch_orb_describe(ctx, img, is, ifr, dblur[l], bs_l, (size_t)bs_l * ih, iw, ih, frames, dfeat[l], dcount + (size_t)l * frames,
+                                         pa.cap_l[l], pattern, dangle[l], ddesc[l]);
+        }
+        ctx->stream = s;
+        if (beside) { (void)hipEventRecord(ctx->lvl_ev[2 * l + 1], chain); ++queued; }
+        if (st != VSLAM_OK) { level_status = st; break; }
         pa.feat[l] = dfeat[l]; pa.angle[l] = dangle[l]; pa.desc[l] = ddesc[l]; pa.scale[l] = ls[l];
     }
+    for (int l = 0; l < queued; ++l) (void)hipStreamWaitEvent(s, ctx->lvl_ev[2 * l + 1], 0);      // the main stream joins every chain, also after an error
+    VSLAM_TRY(level_status);
     pa.level_count = dcount; pa.nl = nl; pa.nlevels_out = p->nlevels; pa.frames = frames; pa.cap = cap;
     pa.out = out; pa.out_angle = angle; pa.out_desc = desc; pa.count = count; pa.level_counts = level_counts;
     hipLaunchKernelGGL(orb_pack_kernel, dim3(frames, pa.nl > 0 ? pa.nl : 1, ORB_PACK_PARTS), dim3(256), 0, s, pa);

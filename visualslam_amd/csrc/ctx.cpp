@@ -280,6 +280,15 @@ vslam_status side_stream_init(vslam_ctx *ctx)
     return VSLAM_OK;
 }
 
+vslam_status level_streams_init(vslam_ctx *ctx)
+{
+    if (ctx->lvl_stream[0]) return VSLAM_OK;
+    VSLAM_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 32; ++i) VSLAM_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lvl_ev[i], hipEventDisableTiming));
+    for (int i = 2; i >= 0; --i) VSLAM_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->lvl_stream[i], hipStreamNonBlocking));
+    return VSLAM_OK;
+}
+
 namespace {
 struct DeviceTurn { std::mutex m; hipEvent_t last = nullptr; int contexts = 0; };
 DeviceTurn g_turn[64];
@@ -460,6 +469,8 @@ vslam_status vslam_ctx_destroy(vslam_ctx *ctx)
     if (ctx->ring) (void)hipHostFree(ctx->ring);
     for (int i = 0; i < 8; ++i) if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    for (int i = 0; i < 3; ++i) if (ctx->lvl_stream[i]) { (void)hipStreamSynchronize(ctx->lvl_stream[i]); (void)hipStreamDestroy(ctx->lvl_stream[i]); }
+    for (int i = 0; i < 32; ++i) if (ctx->lvl_ev[i]) (void)hipEventDestroy(ctx->lvl_ev[i]);
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 3; ++i) if (ctx->tev[i]) (void)hipEventDestroy(ctx->tev[i]);
     if (ctx->flags) (void)hipFree(ctx->flags);
