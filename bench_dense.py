@@ -91,6 +91,27 @@ def run_dense_leg(ctx, dev, stream):
             tf4 = pieces[dom][0] / (pieces[dom][1] * 1e-3) / 1e12
             c4["roofline"] = {"bound": "mfma", "piece": dom, "achieved": tf4, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": tf4 / FP64_MFMA_PEAK_TFLOPS, "traffic": None}
+        # the same update with the state resident in HBM (the bank entry point with one filter): what a caller pays who
+        # keeps the filter on the GPU between frames
+        try:
+            dv4 = torch.device("cuda:0")
+            mu4 = torch.tensor(sc4.x[None], device=dv4)
+            S4 = torch.tensor(np.ascontiguousarray(sc4.S.T)[None], device=dv4)
+            y4 = torch.tensor(sc4.y[None], device=dv4)
+            v4 = torch.tensor(sc4.visible[None].astype(np.uint8), device=dv4)
+            mp4, Sp4 = torch.empty_like(mu4), torch.empty_like(S4)
+            torch.cuda.synchronize()
+            api.measurement_update_iekf_batch_dev(hctx, cam, mu4, S4, y4, v4, sc4.sigma, mp4, Sp4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, it4, st4 = api.measurement_update_iekf_batch_dev(hctx, cam, mu4, S4, y4, v4, sc4.sigma, mp4, Sp4)
+            torch.cuda.synchronize()
+            c4["device_resident_ms"] = (time.perf_counter() - t0) * 1e3
+            c4["device_resident_agrees"] = bool(int(st4[0]) == 0 and int(it4[0]) == int(out4[3]) and
+                                                float(np.abs(mp4[0].cpu().numpy() - out4[1]).max()) <= 1e-9 * max(1.0, float(np.abs(out4[1]).max())))
+            del mu4, S4, mp4, Sp4
+        except Exception as exc:
+            c4["device_resident_error"] = repr(exc)
         # CPU: the oracle's update (analytic derivatives, scalar C, one thread) on the 150-landmark scene; the n = 6012
         # update is O(n^3) per iteration there (host eigensolver) and is extrapolated, not run
         from oracle import pyoracle as orc

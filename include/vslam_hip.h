@@ -232,6 +232,8 @@ vslam_status vslam_measurement_update_iekf(vslam_ctx *ctx, const vslam_camera *c
  * and a solution is used when the radius the reference would set, 0.25 |p|, equals the one solved for to 1e-9
  * relative (VSLAM_BANK_SOLVE_AHEAD=0 in the environment switches this off; the work space grows by up to two
  * n x n matrices per filter for the spare slots).
+ * States of more than 1 024 unknowns do not run in lock step (one such filter fills the GPU): they are updated one after
+ * the other by the single-filter device route, inputs and results staying in device memory.
  * A Hessian that is not positive definite at some iterate is handled within the bank (see CHOLESKY below).
  * status[b]: 0 = mu_post / S_post of filter b are valid; 1 = a subproblem of filter b could not be finished from
  * Cholesky factors (the hard case of the trust-region subproblem, a non-finite Hessian, or a posterior Hessian

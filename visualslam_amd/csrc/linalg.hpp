@@ -142,8 +142,9 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
                                    const PotrfFrom *from = nullptr);
 // from: the matrices to factor are from->H + shift I (same ld); A receives the factors (upper triangles only) without a copy first.
 // listed: `active` holds `batch` matrix indices (the launches cover those matrices only) instead of a mask over `batch` matrices.
+// device_out: mu_post and S_post are device memory (the results stay on the GPU) instead of the caller's host memory.
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
-                                int *status_out);
+                                int *status_out, bool device_out = false);
 
 }  // namespace vslam

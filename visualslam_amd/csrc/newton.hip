@@ -486,7 +486,7 @@ void newton_carve(void *ws, int n, NewtonDevice *w)
 //      should take the eigenvalue route from the start.
 vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, CostDevice *c, void *ws,
                                 double *mu_post, double *S_post, int ldSp, int *fmin_code, int *iters, int *evals_out,
-                                int *status_out)
+                                int *status_out, bool device_out)
 {
     const int n = c->n;
     const size_t nn = (size_t)n * n;
@@ -620,12 +620,17 @@ vslam_status iekf_newton_device(vslam_ctx *ctx, const CamK &k, double sigma, Cos
     VSLAM_TRY(reverse_upper_dev(ctx, w.Hcur, n, w.U, false, 0, 1));
     VSLAM_TRY(potrf_upper_batch_dev(ctx, w.U, n, n, 0, 1, w.info, nullptr, /*zero_lower=*/false));      // the reversal reads the upper tiles only
     VSLAM_TRY(reverse_upper_dev(ctx, w.U, n, c->Hl, true, 0, 1));                                  // Hl, W: scratch from here on
-    const bool piped = n >= PIPELINED_COPY_MIN_N;       // the factor goes home as its upper triangle, the zeros below are written on the host
+    const bool piped = !device_out && n >= PIPELINED_COPY_MIN_N;       // the factor goes home as its upper triangle, the zeros below are written on the host
     VSLAM_TRY(trtri_upper_dev(ctx, c->Hl, n, n, c->W, n, c->tws, /*zero_lower=*/!piped));
     VSLAM_TRY(d2h(ctx, &hinfo, w.info, sizeof(int)));
-    VSLAM_TRY(d2h(ctx, mu_post, w.xcur, (size_t)n * 8));
-    if (piped) VSLAM_TRY(d2h_upper_pipelined(ctx, S_post, (size_t)ldSp, c->W, (size_t)n, n));
-    else VSLAM_TRY(d2h_2d(ctx, S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n));
+    if (device_out) {
+        VSLAM_HIP_TRY(ctx, hipMemcpyAsync(mu_post, w.xcur, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        VSLAM_HIP_TRY(ctx, hipMemcpy2DAsync(S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToDevice, s));
+    } else {
+        VSLAM_TRY(d2h(ctx, mu_post, w.xcur, (size_t)n * 8));
+        if (piped) VSLAM_TRY(d2h_upper_pipelined(ctx, S_post, (size_t)ldSp, c->W, (size_t)n, n));
+        else VSLAM_TRY(d2h_2d(ctx, S_post, (size_t)ldSp * 8, c->W, (size_t)n * 8, (size_t)n * 8, n));
+    }
     VSLAM_TRY(stream_finish(ctx));
     if (hinfo != 0) { *status_out = 1; return VSLAM_OK; }
     *fmin_code = ret; *iters = it; *evals_out = evals;
