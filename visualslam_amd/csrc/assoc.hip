@@ -184,6 +184,25 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
     if (lane == 0) { out[0] = beta0; out[1] = tau0; out[2] = r01; out[3] = beta1; out[4] = tau1; out[5] = p0; out[6] = p1; out[7] = ps; out[8] = (double)(min(last, N - 1) + 1); }
 }
 
+// Before the walk, with the whole chip: the working copy W of SYY, and (mode 0) the individual factors
+// (src/dataAssociation.cpp:165-171), which do not depend on the search.  One workgroup per landmark and instance: its
+// two columns copied, their 2 x 2 R factor by the first wavefront.  (Left to the walking workgroup, the copy of a
+// 4 000 x 4 000 factor and its 2 000 column-pair factors went through one compute unit: most of the call.)
+__global__ __launch_bounds__(256) void assoc_prepare_kernel(AssocArgs a)
+{
+    const int j = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x, N = 2 * a.n;
+    const double *SYY = a.SYY + inst * a.s_S;
+    double *W = a.ws + inst * a.s_ws;
+    const double *c0 = SYY + (size_t)(2 * j) * a.ldS, *c1 = c0 + a.ldS;
+    for (int r = tid; r < N; r += 256) { W[(size_t)(2 * j) * N + r] = c0[r]; W[(size_t)(2 * j + 1) * N + r] = c1[r]; }
+    if (a.mode == 0 && tid < 64) {
+        double r00, r01, r11;
+        wave_qr2(c0, c1, N, &r00, &r01, &r11);
+        double *ind = W + (size_t)N * N + 3 * (size_t)N;
+        if (tid == 0) { ind[3 * j] = r00; ind[3 * j + 1] = r01; ind[3 * j + 2] = r11; }
+    }
+}
+
 __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
 {
     __shared__ double red[AT / 64];
@@ -193,12 +212,15 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     __shared__ int cand_i[AT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, inst = blockIdx.x;
     const int n = a.n, N = 2 * n, m = a.m;
-    const double *muY = a.muY + inst * a.s_mu, *SYY = a.SYY + inst * a.s_S, *y = a.y + inst * a.s_y;
+    const double *muY = a.muY + inst * a.s_mu, *y = a.y + inst * a.s_y;
     int32_t *idx = a.idx + inst * a.s_idx;
-    extern __shared__ double vecs[];         // the 5 N doubles of work vectors when they fit (a.vec_lds)
+    extern __shared__ double vecs[];         // the 3 N doubles of work vectors when they fit (a.vec_lds)
     double *W = a.ws + inst * a.s_ws;        // working copy of SYY (N x N, ld N): accepted reflectors already applied
     double *z = a.vec_lds ? vecs : W + (size_t)N * N;
-    double *ca = z + N, *ind = ca + 2 * N;   // ind[3j..3j+2]: R factor of landmark j's two columns on their own
+    // ind[3j..3j+2]: R factor of landmark j's two columns on their own (assoc_prepare_kernel), in global memory: it is
+    // read once per landmark
+    double *ca = z + N;
+    const double *ind = W + (size_t)N * N + 3 * (size_t)N;
     uint8_t *avail = a.avail + inst * a.s_av;
     const double halflog2pi = log(3.14159265358979323846264338327950288 * 2) / 2;
 
@@ -206,13 +228,6 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     int cursor = 0;                          // state of the offer-list walk (mode 0)
     if (a.mode == 0)
         for (int i = tid; i < m; i += AT) avail[i] = 1;
-    for (size_t e = tid; e < (size_t)N * N; e += AT) W[e] = SYY[(e / N) * a.ldS + (e % N)];
-    if (a.mode == 0)                          // individual factors (src/dataAssociation.cpp:165-171) do not depend on the search: all at once
-        for (int j = wave; j < n; j += AT / 64) {
-            double r00, r01, r11;
-            wave_qr2(SYY + (size_t)(2 * j) * a.ldS, SYY + (size_t)(2 * j + 1) * a.ldS, N, &r00, &r01, &r11);
-            if (lane == 0) { ind[3 * j] = r00; ind[3 * j + 1] = r01; ind[3 * j + 2] = r11; }
-        }
     __syncthreads();
     double zz = 0.0, logdet = 0.0, s = n * a.sU;
     for (int j = 0; j < n; ++j) {
@@ -438,13 +453,14 @@ size_t assoc_ws_doubles(int n) { const size_t N = 2 * (size_t)n; return N * N + 
 // Queues the association kernel for `batch` instances; every pointer is device memory.
 vslam_status assoc_launch(vslam_ctx *ctx, AssocArgs a, int batch)
 {
-    // The work vectors (z, one column pair and the individual factors: 5 N doubles) live in LDS when they fit: every phase
+    // The work vectors (z and one column pair: 3 N doubles) live in LDS when they fit: every phase
     // boundary is then an LDS round trip instead of one through L2.
-    const size_t vec_bytes = (size_t)5 * 2 * a.n * sizeof(double);
+    const size_t vec_bytes = (size_t)3 * 2 * a.n * sizeof(double);
     a.vec_lds = vec_bytes <= 144 * 1024;
     const size_t lds = a.vec_lds ? vec_bytes : 0;
     if (lds > 48 * 1024)
         VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&assoc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(assoc_prepare_kernel, dim3(a.n, batch), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(assoc_kernel, dim3(batch), dim3(AT), lds, ctx->stream, a);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     return VSLAM_OK;
