@@ -134,8 +134,9 @@ __device__ __forceinline__ double wave_sum(double v)
 // workgroup-wide sum costs two barriers of sixteen waves for vectors a single wave holds in a few elements per lane).
 // out: beta0, tau0, r01, beta1, tau1, c0 . z, c1 . z, v1^T v0, and the number of leading rows outside which both
 // reflectors are zero.  On return ca holds the scaled reflector tails as the workgroup-wide routines leave them.
-__device__ void wave_panel(double *ca, const double *z, int k, int N, double *out)
+__device__ void wave_panel(double *ca, const double *z, int k, int N, int rl, double *out)
 {
+    // rl: both columns are zero from row rl on (rl = N when nothing is known)
     const int lane = threadIdx.x & 63;
     double *c0 = ca, *c1 = ca + N;
     // coupling with z_prev (rows < k are not touched below)
@@ -144,7 +145,7 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     // reflector 0 and what it needs of column 1 in one pass
     double t0 = 0.0, d01 = 0.0;
-    for (int r = k + 1 + lane; r < N; r += 64) { const double x = c0[r]; t0 += x * x; d01 += x * c1[r]; }
+    for (int r = k + 1 + lane; r < rl; r += 64) { const double x = c0[r]; t0 += x * x; d01 += x * c1[r]; }
     t0 = wave_sum(t0); d01 = wave_sum(d01);
     const double alpha0 = c0[k];
     double beta0, tau0, scale0;
@@ -160,7 +161,7 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
     // scale the tail of column 0, apply the reflector to column 1, and gather reflector 1's sums on the way
     double t1 = 0.0;
     int last = k + 1;                                            // last row in which a reflector can be non-zero
-    for (int r = k + 1 + lane; r < N; r += 64) {
+    for (int r = k + 1 + lane; r < rl; r += 64) {
         const double v = c0[r] * scale0, y = c1[r] - d * v;
         c0[r] = v; c1[r] = y;
         if (r > k + 1) t1 += y * y;
@@ -179,7 +180,7 @@ __device__ void wave_panel(double *ca, const double *z, int k, int N, double *ou
         tau1 = (beta1 - alpha1) / beta1;
     }
     double ps = 0.0;                                             // v1^T v0 = v0(k+1) + sum_{r >= k+2} v0(r) v1(r)
-    for (int r = k + 2 + lane; r < N; r += 64) { const double v = c1[r] * scale1; c1[r] = v; ps += c0[r] * v; }
+    for (int r = k + 2 + lane; r < rl; r += 64) { const double v = c1[r] * scale1; c1[r] = v; ps += c0[r] * v; }
     ps = wave_sum(ps) + ((k + 1 < N) ? c0[k + 1] : 0.0);
     if (lane == 0) { out[0] = beta0; out[1] = tau0; out[2] = r01; out[3] = beta1; out[4] = tau1; out[5] = p0; out[6] = p1; out[7] = ps; out[8] = (double)(min(last, N - 1) + 1); }
 }
@@ -194,7 +195,18 @@ __global__ __launch_bounds__(256) void assoc_prepare_kernel(AssocArgs a)
     const double *SYY = a.SYY + inst * a.s_S;
     double *W = a.ws + inst * a.s_ws;
     const double *c0 = SYY + (size_t)(2 * j) * a.ldS, *c1 = c0 + a.ldS;
-    for (int r = tid; r < N; r += 256) { W[(size_t)(2 * j) * N + r] = c0[r]; W[(size_t)(2 * j + 1) * N + r] = c1[r]; }
+    __shared__ int ext_s;
+    if (tid == 0) ext_s = 0;
+    __syncthreads();
+    int last = 0;                                            // 1 + the last row in which either column is non-zero
+    for (int r = tid; r < N; r += 256) {
+        const double v0 = c0[r], v1 = c1[r];
+        W[(size_t)(2 * j) * N + r] = v0; W[(size_t)(2 * j + 1) * N + r] = v1;
+        if (v0 != 0.0 || v1 != 0.0) last = r + 1;
+    }
+    atomicMax(&ext_s, last);
+    __syncthreads();
+    if (tid == 0) (W + (size_t)N * N + 3 * (size_t)N + 3 * (size_t)a.n)[j] = (double)ext_s;      // ext[j], behind ind
     if (a.mode == 0 && tid < 64) {
         double r00, r01, r11;
         wave_qr2(c0, c1, N, &r00, &r01, &r11);
@@ -220,11 +232,12 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
     // ind[3j..3j+2]: R factor of landmark j's two columns on their own (assoc_prepare_kernel), in global memory: it is
     // read once per landmark
     double *ca = z + N;
-    const double *ind = W + (size_t)N * N + 3 * (size_t)N;
+    const double *ind = W + (size_t)N * N + 3 * (size_t)N, *ext = ind + 3 * (size_t)n;       // ext[j]: rows of landmark j's columns that can be non-zero
     uint8_t *avail = a.avail + inst * a.s_av;
     const double halflog2pi = log(3.14159265358979323846264338327950288 * 2) / 2;
 
     int k = 0, nA = 0;                       // accepted reflectors / associated landmarks
+    int rlim = 0;                            // no column met so far (nor any reflector made from them) reaches row rlim or beyond
     int cursor = 0;                          // state of the offer-list walk (mode 0)
     if (a.mode == 0)
         for (int i = tid; i < m; i += AT) avail[i] = 1;
@@ -234,16 +247,19 @@ __global__ __launch_bounds__(AT) void assoc_kernel(AssocArgs a)
         const int given = a.mode == 1 ? idx[j] : -2;
         if (a.mode == 1 && given == -1) continue;
         // ---- landmark j's two columns from the working copy (the accepted reflectors are in) ----
-        for (int r = tid; r < 2 * N; r += AT) ca[r] = W[(size_t)(2 * j) * N + r];
+        // an upper-triangular factor (what affineTransform returns) has nothing below row 2 j + 1 in these columns, and the
+        // reflectors of earlier landmarks, made from shorter columns, put nothing there either
+        rlim = a.vec_lds ? min(N, max(rlim, max((int)ext[j], k + 2))) : N;      // the pivots' rows k, k + 1 are always inside
+        for (int r = tid; r < rlim; r += AT) { ca[r] = W[(size_t)(2 * j) * N + r]; ca[N + r] = W[(size_t)(2 * j + 1) * N + r]; }
         __syncthreads();
         // ---- two new reflectors on rows k.. (joint factor) ----
         double tau0, tau1, beta0, beta1, r01, c0, c1, s01 = 0.0;
         int rmax = N;                        // rows k .. rmax - 1 are all the new reflectors touch
         if (a.vec_lds) {
             // the vectors live in LDS: one wave does the serial part, everybody else meets it at one barrier
-            if (wave == 0) wave_panel(ca, z, k, N, pn);
+            if (wave == 0) wave_panel(ca, z, k, N, rlim, pn);
             __syncthreads();
-            beta0 = pn[0]; tau0 = pn[1]; r01 = pn[2]; beta1 = pn[3]; tau1 = pn[4]; c0 = pn[5]; c1 = pn[6]; s01 = pn[7]; rmax = (int)pn[8];
+            beta0 = pn[0]; tau0 = pn[1]; r01 = pn[2]; beta1 = pn[3]; tau1 = pn[4]; c0 = pn[5]; c1 = pn[6]; s01 = pn[7]; rmax = min((int)pn[8], rlim);
         } else {
             beta0 = make_reflector(ca, k, N, red, &tau0);
             apply_reflector(ca, tau0, k, N, ca + N, red);
