@@ -55,7 +55,7 @@ def _density(L, seed, m_extra, noise):
     return sc, y, orc
 
 
-@pytest.mark.parametrize("L,seed,enforce", [(1, 3, False), (4, 5, False), (9, 11, False), (9, 12, True), (16, 21, False)])
+@pytest.mark.parametrize("L,seed,enforce", [(1, 3, False), (4, 5, False), (9, 11, False), (9, 12, True), (16, 21, False), (60, 33, False), (60, 34, True)])
 def test_snn_vs_oracle(ctx, gcam, ocam, L, seed, enforce):
     """snn end to end (bundle -> affineTransform -> greedy search): same association vector as the oracle's
     literal restatement (which re-factors per candidate like the reference) and the same surprisal."""
