@@ -109,6 +109,23 @@ def run_dense_leg(ctx, dev, stream):
             c4["device_resident_ms"] = (time.perf_counter() - t0) * 1e3
             c4["device_resident_agrees"] = bool(int(st4[0]) == 0 and int(it4[0]) == int(out4[3]) and
                                                 float(np.abs(mp4[0].cpu().numpy() - out4[1]).max()) <= 1e-9 * max(1.0, float(np.abs(out4[1]).max())))
+            # the two steps in front of the update, device resident as well: predicted measurement density and association
+            L4 = (n4 - 12) // 3
+            muy4 = torch.zeros((1, 2 * L4), dtype=torch.float64, device=dv4)
+            Syy4 = torch.zeros((1, 2 * L4, 2 * L4), dtype=torch.float64, device=dv4)
+            rng4 = np.random.default_rng(0)
+            f4 = np.concatenate([sc4.pixel_true + rng4.standard_normal((L4, 2)), rng4.uniform(0, 1000, (100, 2))])
+            yt4 = torch.tensor(f4[None], device=dv4)
+            idx4 = torch.zeros((1, L4), dtype=torch.int32, device=dv4)
+            sur4 = torch.zeros(1, dtype=torch.float64, device=dv4)
+            for label, fn in (("affine_bundle_device_resident_ms", lambda: api.affine_bundle_batch_dev(hctx, cam, mu4, S4, muy4, Syy4)),
+                              ("snn_density_device_resident_ms", lambda: api.snn_density_batch_dev(hctx, muy4, Syy4, yt4, L4, f4.shape[0], 1920, 1080, idx4, sur4))):
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn(); torch.cuda.synchronize()
+                c4[label] = (time.perf_counter() - t0) * 1e3
+            c4["snn_density_associated"] = int((idx4 >= 0).sum().item())
+            del muy4, Syy4
             del mu4, S4, mp4, Sp4
         except Exception as exc:
             c4["device_resident_error"] = repr(exc)
