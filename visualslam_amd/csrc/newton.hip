@@ -336,9 +336,10 @@ vslam_status potrf_upper_batch_dev(vslam_ctx *ctx, double *A, int n, int lda, si
     // Banks take the trailing update two block rows at a time: after the row panel of block row k only block row k + 1 is
     // updated (a strip of tiles, whose first one factors the next diagonal block), its row panel is solved, and the rest of
     // the trailing matrix then receives both block rows in one pass with K = 128 -- the read-modify-write of C, which is
-    // what a bank's update launches spend their time on, happens once per 128 columns.  One matrix gains nothing from it
-    // (its launches are as long as the chain of diagonal blocks) and keeps the one-level form, bit for bit.
-    const bool two_level = batch >= 16 && !getenv("VSLAM_POTRF_ONE_LEVEL");
+    // what a bank's update launches spend their time on, happens once per 128 columns.  A large matrix gains a little too
+    // (n = 6012: 88.6 -> 86.2 ms per update); a small single one gains nothing (its launches are as long as the chain of
+    // diagonal blocks) and keeps the one-level form, bit for bit.
+    const bool two_level = (batch >= 16 || n >= 2048) && !getenv("VSLAM_POTRF_ONE_LEVEL");
     auto launch_trsm = [&](int j0, int rest) {
         hipLaunchKernelGGL(potrf_trsm_kernel, dim3((rest + extra + CB - 1) / CB, batch), dim3(256), 0, s, A, lda, n, j0, strideA, active, listed ? 1 : 0, dinv, (size_t)1024,
                            rhs, stride_rhs);
