@@ -21,6 +21,7 @@
 #include "linalg.hpp"
 
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 namespace vslam {
@@ -493,11 +494,29 @@ namespace {
 // chi2 LUT of snn (src/dataAssociation.cpp:27-29, 63-69) on the device.
 vslam_status upload_lut(vslam_ctx *ctx, int n, double *dlut)
 {
-    std::vector<double> lut((size_t)n);
-    const double c = 2 * normcdf_host(3.0) - 1;
-    for (int k = 0; k < n; ++k) lut[(size_t)k] = chi2inv_host(c, 2.0 * (k + 1));
-    VSLAM_TRY(h2d(ctx, dlut, lut.data(), (size_t)n * 8));
-    return stream_sync(ctx);                      // lut goes out of scope
+    // The gates chi2inv(c, 2 (k + 1)) depend on nothing but k: computed once per process (each is an iteration on the
+    // incomplete gamma function; at 2 000 landmarks they took longer than the kernel) and kept at a fixed address, so
+    // the copy below may still be in flight when this function returns.
+    constexpr int kLutMax = 32768;
+    static double table[kLutMax];
+    static int filled = 0;
+    static std::mutex mtx;
+    if (n > kLutMax) {
+        std::vector<double> lut((size_t)n);
+        const double c = 2 * normcdf_host(3.0) - 1;
+        for (int k = 0; k < n; ++k) lut[(size_t)k] = chi2inv_host(c, 2.0 * (k + 1));
+        VSLAM_TRY(h2d(ctx, dlut, lut.data(), (size_t)n * 8));
+        return stream_sync(ctx);                  // lut goes out of scope
+    }
+    {
+        std::lock_guard<std::mutex> lock(mtx);
+        if (filled < n) {
+            const double c = 2 * normcdf_host(3.0) - 1;
+            for (int k = filled; k < n; ++k) table[k] = chi2inv_host(c, 2.0 * (k + 1));
+            filled = n;
+        }
+    }
+    return h2d(ctx, dlut, table, (size_t)n * 8);
 }
 }  // namespace
 
