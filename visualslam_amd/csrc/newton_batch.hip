@@ -769,8 +769,12 @@ extern "C" vslam_status vslam_measurement_update_iekf_batch_dev(vslam_ctx *ctx, 
         }
         return VSLAM_OK;
     }
-    // instances per pass: the work matrices of one pass stay under 16 GiB
-    size_t chunk = ((size_t)16 << 30) / (8 * nn * 8);
+    // instances per pass: the work matrices of one pass stay under 64 GiB of the 288 GB (VSLAM_BANK_PASS_GIB: another limit).
+    // Larger passes amortise the rounds in which few filters are still busy: 4 096 filters of 150 landmarks take 279 ms in
+    // one pass (14 700 updates/s), 2 048 filters 153 ms in one pass against 165 ms in two.
+    size_t pass_gib = 64;
+    if (const char *e = getenv("VSLAM_BANK_PASS_GIB")) { const long v = atol(e); if (v >= 1 && v <= 200) pass_gib = (size_t)v; }
+    size_t chunk = (pass_gib << 30) / (8 * nn * 8);
     chunk = std::max<size_t>(1, std::min<size_t>(chunk, 16384));
     for (int b0 = 0; b0 < batch; b0 += (int)chunk) {
         const int B = std::min<int>((int)chunk, batch - b0);
