@@ -313,6 +313,16 @@ def run_dense_leg(ctx, dev, stream):
     upd["bank_512_lock_step_updates_per_s"] = rate512
     upd["bank_512_lock_step_ms"] = dt512 * 1e3
     upd["bank_512_handed_back_unfinished"] = nfail          # filters the device route could not finish (hard case); not counted in the rate
+    try:        # the bank at the size of BASELINE configs[4] on one GPU: 4 096 filters, one pass of 56 GB of work space
+        import torch
+        torch.cuda.empty_cache()
+        rate4k, dt4k, nfail4k, _ = batched_throughput(150, 4096, dev.index or 0, reps=1)
+        upd["bank_4096_lock_step_updates_per_s"] = rate4k
+        upd["bank_4096_lock_step_ms"] = dt4k * 1e3
+        upd["bank_4096_handed_back_unfinished"] = nfail4k
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        upd["bank_4096_error"] = repr(exc)
     return {
         "frame_steps_150_landmarks": frame,
         "qr": {"workload": "in-place Householder QR (R only), %d x %d fp64, device resident" % (n, n), "ms": ms,
