@@ -209,27 +209,28 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one pair of HIP events around the K steps, on the kernels' stream: an event record between two steps is a packet
+    # of its own in the queue and costs the stream about 5 us each, 6 % of a step of this length
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record(stream)
     for i in range(args.steps):
-        ev[i][0].record(stream)
         step()
-        ev[i][1].record(stream)
+    ev_b.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_ms = float(np.mean(step_ms))
+    kern_ms = ev_a.elapsed_time(ev_b) / args.steps
     elapsed = sharding.max_over_ranks(elapsed, device=dev)
-    # median and inter-quartile range over at least 30 steps: the K timed steps plus, when K < 30, further steps
-    # taken after the timed region (they do not enter `value`)
-    extra = max(0, 30 - args.steps)
+    # spread of single steps: 30 further steps after the timed region, each between its own pair of events (these
+    # carry the cost of the event records and do not enter `value` or the roofline figures)
+    extra = 30
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(extra)]
     for a, b in ev2:
         a.record(stream)
         step()
         b.record(stream)
     torch.cuda.synchronize()
-    step_ms += [a.elapsed_time(b) for a, b in ev2]
+    step_ms = [a.elapsed_time(b) for a, b in ev2]
     q1, med, q3 = (float(v) for v in np.percentile(step_ms, [25, 50, 75]))
     # results to rank 0 (outside the timed region): the only exchange a sharded batch needs
     all_vals = sharding.gather_to_root(val)
@@ -290,6 +291,34 @@ def main():
     torch.cuda.synchronize()
     single_us = e0.elapsed_time(e1) / 200 * 1e3
 
+    # the same call on the whole 4 096-instance batch of BASELINE configs[4] held by one GPU (reported beside the
+    # headline, never in place of it: the headline keeps 512 instances per GPU, configs[4]'s share of one of 8 GPUs)
+    whole_batch = None
+    if rank == 0 and world == 1 and B < 4096:
+        B4 = 4096
+        r4 = (B4 + uniq - 1) // uniq
+        x4 = torch.tensor(np.tile(xs, (r4, 1))[:B4] + 1e-3 * rng.standard_normal((B4, n)), device=dev)
+        y4 = torch.tensor(np.tile(ys, (r4, 1))[:B4], device=dev)
+        v4 = torch.tensor(np.tile(vs, (r4, 1))[:B4], device=dev)
+        val4 = torch.empty(B4, dtype=torch.float64, device=dev)
+        g4 = torch.empty((B4, n), dtype=torch.float64, device=dev)
+        H4 = torch.empty((B4, n, n), dtype=torch.float64, device=dev)
+        code4 = torch.empty((B4, L), dtype=torch.int32, device=dev)
+        for _ in range(3):
+            api.point_loglik_batch_dev(ctx, cam, n, x4, y4, v4, SIGMA, val4, g4, H4, code4)
+        e4a, e4b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e4a.record(stream)
+        for _ in range(30):
+            api.point_loglik_batch_dev(ctx, cam, n, x4, y4, v4, SIGMA, val4, g4, H4, code4)
+        e4b.record(stream)
+        torch.cuda.synchronize()
+        ms4 = e4a.elapsed_time(e4b) / 30
+        whole_batch = {"instances": B4, "ms_per_call": ms4, "landmark_updates_per_s": B4 * L / (ms4 * 1e-3),
+                       "frac_of_hbm_roof": loglik_algorithmic_bytes(n, L) * B4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "all_finite": bool(torch.isfinite(val4).all().item()),
+                       "note": "30 calls between one pair of HIP events, after the timed region; same kernels, 8x the instances per launch"}
+        del x4, y4, v4, val4, g4, H4, code4
+
     corner = None
     if not args.no_corner:
         try:
@@ -331,8 +360,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "step_stats": {"samples": len(step_ms), "median_ms": med, "q1_ms": q1, "q3_ms": q3, "iqr_ms": q3 - q1,
                            "median_frac_of_hbm_roof": loglik_algorithmic_bytes(n, L) * B / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "HIP-event time of each step on the kernels' stream; the K timed steps%s" % (
-                               " plus %d steps after the timed region" % extra if extra else "")},
+                           "note": "%d steps after the timed region, each between its own pair of HIP events on the kernels' "
+                                   "stream; the event records add about 10 us to a step timed this way, which the timed "
+                                   "region (one pair of events around all K steps) does not pay" % extra},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3 x%d: %d independent point-landmark updates per GPU per step, L=150 landmarks, "
                                    "n=462 states, log-lik + gradient + exact Hessian (BASELINE configs[2] batched as configs[4])"
@@ -355,6 +385,8 @@ def main():
         }
         if share_gpu or backend != "nccl":
             out["rehearsal"] = "ranks share GPU 0 = %s, backend %s: exercises the multi-rank code path only, the numbers are not a measurement" % (share_gpu, backend)
+        if whole_batch is not None:
+            out["whole_configs4_batch_on_one_gpu"] = whole_batch
         if corner is not None:
             out["corner"] = corner
         if dense is not None:
