@@ -334,9 +334,39 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(CornerArgs a)
 //   -> responses of row t-4 -> non-maximum suppression of row t-5.
 // Same integer and float operations per pixel as corner_tile_kernel, so the keypoints are identical.
 constexpr int SW_HALO = 6, SW_OUT = 128 - 2 * SW_HALO;
+typedef short sw_short2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_read_i(int v, int addr) { return __builtin_amdgcn_ds_bpermute(addr, v); }
 __device__ __forceinline__ float lane_read_f(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+
+// Maxima without the quieting of signalling NaNs that fmaxf asks of the compiler (a v_max_f32 x, x, x in front of every
+// value that arrives from another lane): the responses compared here are finite.
+__device__ __forceinline__ float max3_raw(float x, float y, float z)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float max2_raw(float x, float y)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// Correctly rounded square root of x = 0 or a normal number far from both ends of the range (the sums of squares of the
+// Shi-Tomasi response): the hardware estimate (within one unit in the last place) and the step to the neighbour whose
+// residual says so, as the compiler's sqrtf does it -- without that routine's rescaling of tiny arguments and its test
+// for zero and infinity (for x = 0 both residual tests fail and 0 stays).  Checked against sqrtf over every such x by
+// vslam_debug_sqrtf_mismatches.
+__device__ __forceinline__ float sqrt_rn_normal(float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float yd = __int_as_float(__float_as_int(y) - 1), yu = __int_as_float(__float_as_int(y) + 1);
+    const float rd = __builtin_fmaf(-yd, y, x), ru = __builtin_fmaf(-yu, y, x);
+    float r = (rd <= 0.0f) ? yd : y;
+    r = (ru > 0.0f) ? yu : r;
+    return r;
+}
 
 template <int DET>
 __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstrips, int nseg, int seg_h)
@@ -358,7 +388,13 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
     if (ya >= yb) return;
     const int gx0 = strip * SW_OUT - SW_HALO + 2 * lane;      // column E; O is gx0 + 1
     const uint8_t *gray = a.gray + (size_t)frame * a.stride_frame;
-    const uint8_t *colp[2] = {gray + min(max(gx0, 0), w - 1), gray + min(max(gx0 + 1, 0), w - 1)};
+    // A lane fetches its column pair with one two-byte load (gx0 is even; the address need not be).  Pairs that stick out
+    // of the image are pulled back inside: the columns outside then hold pixels of other columns, which only ever reach
+    // responses that col_valid discards (a valid response reads the columns gx - 4 ... gx + 4, all inside) -- except that
+    // with an odd width the last column, w - 1, is the E of a pair pulled back by one and sits in the second byte.
+    const int cx = min(max(gx0, 0), w - 2);
+    const unsigned pair_off = (unsigned)cx;
+    const uint32_t pair_sel = (gx0 - cx == 1) ? 0x0c010c01u : 0x0c010c00u;     // v_perm: bytes -> {E, O} as two 16-bit values
     // byte addresses of the neighbouring lanes for ds_bpermute (wrapping; wrapped values only reach halo columns)
     const int am1 = ((lane - 1) & 63) << 2, ap1 = ((lane + 1) & 63) << 2, am2 = ((lane - 2) & 63) << 2, ap2 = ((lane + 2) & 63) << 2;
     constexpr int R = 4;                                      // response needs the image +-R (7x7 window of 3x3 gradients)
@@ -375,7 +411,7 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
     for (int e = 0; e < 2; ++e) { thr_col[0][e] = col_out[e] ? a.thr_h : INFINITY; thr_col[1][e] = col_out[e] ? a.thr_s : INFINITY; }
     int cnt[2] = {0, 0};                                      // staged keys per detector (wave-uniform)
 
-    int r0[2] = {0, 0}, r1[2] = {0, 0}, r2[2] = {0, 0};       // pixel rows t-2, t-1, t
+    uint32_t r0 = 0, r1 = 0, r2 = 0;                          // pixel rows t-2, t-1, t: {E, O} as two 16-bit values
     int ring[7][2][3];
 #pragma unroll
     for (int u = 0; u < 7; ++u)
@@ -407,34 +443,36 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
     };
 
     const int tstart = ya - 6, tend = yb + 5;                 // steps [tstart, tend), run in blocks of 7 (the ring size)
-    int nxt[7][2];
+    auto fetch_pair = [&](int row) -> uint32_t {            // the row's address is wave-uniform, the column offset a 32-bit register
+        const size_t ro = (size_t)min(max(row, 0), h - 1) * a.stride;
+        const uint8_t *rp = gray + (((size_t)__builtin_amdgcn_readfirstlane((int)(ro >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ro));
+        uint16_t v;
+        __builtin_memcpy(&v, rp + pair_off, 2);
+        return v;
+    };
+    uint32_t nxt[7];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        const size_t ro = (size_t)min(max(tstart + u, 0), h - 1) * a.stride;
-        nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
-    }
+    for (int u = 0; u < 7; ++u) nxt[u] = fetch_pair(tstart + u);
     for (int t0 = tstart; t0 < tend; t0 += 7) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {                          // steps past tend only touch rows no band emits
             const int t = t0 + u;
-            const int pix[2] = {nxt[u][0], nxt[u][1]};
-            {                                                  // row t + 7 takes this slot: seven rows stay in flight
-                const size_t ro = (size_t)min(max(t + 7, 0), h - 1) * a.stride;
-                nxt[u][0] = colp[0][ro]; nxt[u][1] = colp[1][ro];
-            }
-            int sm[2], df[2], pk[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                r0[e] = r1[e]; r1[e] = r2[e]; r2[e] = pix[e];
-                sm[e] = r0[e] + 2 * r1[e] + r2[e];             // Sobel of row t-1, separable: smooth and difference
-                df[e] = r2[e] - r0[e];
-                pk[e] = (sm[e] << 16) | (df[e] & 0xffff);
-            }
-            const int pk_l = lane_read_i(pk[1], am1), pk_r = lane_read_i(pk[0], ap1);   // O of lane l-1, E of lane l+1
-            const int sm_l = (int)((unsigned)pk_l >> 16), df_l = (pk_l << 16) >> 16;
-            const int sm_r = (int)((unsigned)pk_r >> 16), df_r = (pk_r << 16) >> 16;
-            const int ix[2] = {sm[1] - sm_l, sm_r - sm[0]};
-            const int iy[2] = {df_l + 2 * df[0] + df[1], df[0] + 2 * df[1] + df_r};
+            const uint32_t pix = __builtin_amdgcn_perm(nxt[u], nxt[u], pair_sel);
+            nxt[u] = fetch_pair(t + 7);                        // row t + 7 takes this slot: seven rows stay in flight
+            // Sobel of row t-1, separable (smooth and difference), both columns of the pair in one register: the sums stay
+            // below 2^16 (4 * 255), the differences are 16-bit two's complement
+            r0 = r1; r1 = r2; r2 = pix;
+            const uint32_t smp = r0 + 2 * r1 + r2;
+            const uint32_t dfp = __builtin_bit_cast(uint32_t, __builtin_bit_cast(sw_short2, r2) - __builtin_bit_cast(sw_short2, r0));
+            // to the right-hand neighbour: {sum, difference} of O; to the left-hand one: those of E
+            const int pk_l = lane_read_i((int)__builtin_amdgcn_perm(smp, dfp, 0x07060302u), am1);   // O of lane l-1
+            const int pk_r = lane_read_i((int)__builtin_amdgcn_perm(smp, dfp, 0x05040100u), ap1);   // E of lane l+1
+            const int ix[2] = {(int)(smp >> 16) - (int)((unsigned)pk_l >> 16), (int)((unsigned)pk_r >> 16) - (int)(smp & 0xffffu)};
+            // {df_l + 2 dfE + dfO, dfE + 2 dfO + df_r}
+            const sw_short2 dfs = __builtin_bit_cast(sw_short2, dfp);
+            const sw_short2 iyp = dfs + dfs + __builtin_bit_cast(sw_short2, __builtin_amdgcn_alignbit(dfp, dfp, 16)) +
+                                  __builtin_bit_cast(sw_short2, __builtin_amdgcn_perm((uint32_t)pk_r, (uint32_t)pk_l, 0x05040100u));
+            const int iy[2] = {(int)iyp.x, (int)iyp.y};
             int hs[2][3];                                      // horizontal 7-sums of the products
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
@@ -463,7 +501,7 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
                 }
                 if (DET & 2) {
                     const float m = __fmul_rn(t4, 0.5f), d = __fmul_rn(__fsub_rn(fa, fb), 0.5f);
-                    const float root = sqrtf(__fadd_rn(__fmul_rn(d, d), t2));     // correctly rounded (see vslam_debug_sqrtf_mismatches)
+                    const float root = sqrt_rn_normal(__fadd_rn(__fmul_rn(d, d), t2));     // 0 or >= 1/4: squares of halves of integers
                     resp[1][e] = valid ? __fmul_rn(__fsub_rn(m, root), a.s2) : 0.0f;
                 }
             }
@@ -475,12 +513,12 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
                 if (!(DET & (1 << det))) continue;
                 const float re = resp[det][0], ro = resp[det][1];
                 const float l = lane_read_f(ro, am1), rr = lane_read_f(re, ap1);       // left of E, right of O
-                const float m_dn[2] = {fmaxf(fmaxf(l, re), ro), fmaxf(fmaxf(re, ro), rr)};
+                const float m_dn[2] = {max3_raw(l, re, ro), max3_raw(re, ro, rr)};
                 const float ce = cv[det][0], co = cv[det][1];
                 // strictly above the threshold, the row above and the left neighbour; at least the right neighbour and the row below
-                const bool hit_e = ce > fmaxf(fmaxf(thr_col[det][0], m_up[det][0]), cl[det]) && ce >= fmaxf(co, m_dn[0]);
-                const bool hit_o = co > fmaxf(fmaxf(thr_col[det][1], m_up[det][1]), ce) && co >= fmaxf(cr[det], m_dn[1]);
-                if (row_out && __ballot(hit_e || hit_o)) {
+                const bool hit_e = (int)(ce > max3_raw(thr_col[det][0], m_up[det][0], cl[det])) & (int)(ce >= max2_raw(co, m_dn[0]));
+                const bool hit_o = (int)(co > max3_raw(thr_col[det][1], m_up[det][1], ce)) & (int)(co >= max2_raw(cr[det], m_dn[1]));
+                if (row_out && __builtin_amdgcn_ballot_w64((int)hit_e | (int)hit_o)) {
                     emit(det, hit_e, ce, gx0, yc);
                     emit(det, hit_o, co, gx0 + 1, yc);
                 }
@@ -1297,14 +1335,17 @@ static vslam_status ensure_lds_attr(vslam_ctx *ctx)
 }
 
 // Counts the non-negative finite floats x for which sqrtf(x) differs from the correctly rounded
-// square root (float)sqrt((double)x) (exact: 53 >= 2*24 + 2 bits).
+// square root (float)sqrt((double)x) (exact: 53 >= 2*24 + 2 bits), plus those among x = 0 and x >= 2^-64 for which
+// sqrt_rn_normal(x), the form the sliding-window detector uses on its sums of squares, does.
 __global__ void sqrtf_check_kernel(unsigned long long *bad)
 {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long mine = 0;
     for (unsigned long long u = tid; u < 0x7f800000ull; u += (unsigned long long)gridDim.x * blockDim.x) {
         const float x = __uint_as_float((unsigned)u);
-        mine += __float_as_uint(sqrtf(x)) != __float_as_uint((float)sqrt((double)x));
+        const unsigned exact = __float_as_uint((float)sqrt((double)x));
+        mine += __float_as_uint(sqrtf(x)) != exact;
+        if (u == 0 || u >= 0x1f800000ull) mine += __float_as_uint(sqrt_rn_normal(x)) != exact;
     }
     if (mine) atomicAdd(bad, mine);
 }
