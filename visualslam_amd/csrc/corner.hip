@@ -1253,7 +1253,9 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
     if (a.bs == 7 && !getenv("VSLAM_CORNER_TILE")) {
         const int nstrips = (a.w + SW_OUT - 1) / SW_OUT;
         // bands of rows: enough wavefronts to fill the chip, at least 64 rows each (11 extra steps per band)
-        int nseg = (8192 + nstrips * frames - 1) / (nstrips * frames);
+        int target_waves = 8192;
+        if (const char *e = getenv("VSLAM_STRIP_WAVES")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 20)) target_waves = v; }      // A/B runs
+        int nseg = (target_waves + nstrips * frames - 1) / (nstrips * frames);
         const int max_seg = (a.h + 63) / 64;
         if (nseg > max_seg) nseg = max_seg;
         if (nseg < 1) nseg = 1;
