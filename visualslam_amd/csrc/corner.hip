@@ -28,6 +28,7 @@
 // keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
 // unpacks the leading keys into Feature records.
 #include "common.hpp"
+#include <type_traits>
 #include "orb.hpp"
 
 #include <cmath>
@@ -588,17 +589,45 @@ __global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const 
         }
         __syncthreads();
     };
+    auto strided_passes = [&](int k, int jhi, auto NP) {
+        constexpr int np = decltype(NP)::value, nk = 1 << np;
+        const int jlo = jhi >> (np - 1);
+        for (int t = tid; t < S / nk; t += 1024) {
+            const int low = t & (jlo - 1), base = (t - low) * nk + low;
+            const bool desc = (base & k) == 0;
+            uint64_t r[nk];
+#pragma unroll
+            for (int q = 0; q < nk; ++q) r[q] = keys[base + q * jlo];
+#pragma unroll
+            for (int jj = nk / 2; jj > 0; jj >>= 1) {
+#pragma unroll
+                for (int q = 0; q < nk; ++q) {
+                    if ((q & jj) == 0) {
+                        const uint64_t a = r[q], b = r[q | jj];
+                        const bool sw = (a < b) == desc;
+                        r[q] = sw ? b : a; r[q | jj] = sw ? a : b;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < nk; ++q) keys[base + q * jlo] = r[q];
+        }
+        __syncthreads();
+    };
     local_passes(2, LB);
     for (int k = 2 * LB; k <= S; k <<= 1) {
-        for (int j = k >> 1; j >= LB; j >>= 1) {
-            for (int t = tid; t < (S >> 1); t += 1024) {
-                int i = 2 * t - (t & (j - 1));          // lower index of the pair
-                int p = i + j;
-                bool desc = (i & k) == 0;
-                uint64_t a = keys[i], b = keys[p];
-                if ((a < b) == desc) { keys[i] = b; keys[p] = a; }
-            }
-            __syncthreads();
+        // The passes with partner distance >= LB of a stage, up to three at a time: the passes jhi, jhi/2, jhi/4 only ever
+        // pair keys whose indices differ in those three bits, so a thread takes the eight keys base + q * (jhi/4) into
+        // registers and runs the three passes without a barrier in between (their direction is that of bit k of base,
+        // which the eight indices share: 2 * jhi <= k).
+        int c = 0;
+        for (int j = k >> 1; j >= LB; j >>= 1) ++c;
+        for (int jhi = k >> 1; c > 0;) {
+            const int np = c < 3 ? c : 3;
+            if (np == 3) strided_passes(k, jhi, std::integral_constant<int, 3>());
+            else if (np == 2) strided_passes(k, jhi, std::integral_constant<int, 2>());
+            else strided_passes(k, jhi, std::integral_constant<int, 1>());
+            jhi >>= np; c -= np;
         }
         local_passes(k, k);
     }
