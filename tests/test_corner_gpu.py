@@ -70,13 +70,15 @@ def test_keypoints_identical(ctx, name, kw):
             assert np.all(np.diff(got["score"]) <= 0), "sorted by score, descending (imagefeatures.cpp:20-22)"
 
 
-def test_many_candidates_merge_path(ctx):
-    """> 16384 candidates per detector: exercises the chunk-merge kernels."""
+@pytest.mark.parametrize("harris_thresh,shi_thresh", [(0.0055, 0.068),      # 18436 / 25614 candidates: two chunks of 16384
+                                                      (0.004, 0.058)])      # 49053 / 58067: three and four chunks
+def test_many_candidates_merge_path(ctx, harris_thresh, shi_thresh):
+    """> 16384 candidates per detector: exercises the chunk-merge kernel."""
     from oracle import pyoracle as orc
     from visualslam_amd import api
     rng = np.random.default_rng(5)
     gray = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)       # pure noise: corners everywhere
-    kw = dict(harris_thresh=0.0055, shi_thresh=0.068, max_features=16384)   # 18436 / 25614 candidates
+    kw = dict(harris_thresh=harris_thresh, shi_thresh=shi_thresh, max_features=16384)
     gp, op = api.corner_params(**kw), orc.corner_params(**kw)
     for det in (0, 1):
         want = orc.corner_detect(gray, op, det, cap=16384)

@@ -23,9 +23,10 @@
 // -> response -> NMS all stay in LDS.  Survivors are staged in LDS and appended
 // with one atomic reservation per workgroup to a per-frame candidate list of
 // 64-bit sort keys that encode score, y and x.
-// Kernel 2 (sort_chunk_kernel): bitonic sort of up to 16384 keys in LDS by one
-// 1024-thread workgroup per chunk; kernel 3 merges sorted chunks pairwise
-// keeping the top 16384 (enough for any max_features <= 16384).  Kernel 4
+// Kernel 2 (sort_chunk_kernel): bitonic sort of parts of 2048 keys in LDS, one
+// 256-thread workgroup per part; merge_parts_kernel joins the parts of a chunk
+// of 16384 keys in LDS; merge_chunks_kernel merges the chunks of a longer list
+// keeping the top 16384 (enough for any max_features <= 16384).  The last kernel
 // unpacks the leading keys into Feature records.
 #include "common.hpp"
 #include <type_traits>
@@ -540,31 +541,33 @@ __global__ __launch_bounds__(64) void corner_strip_kernel(CornerArgs a, int nstr
     }
 }
 
-// Bitonic sort (descending) of one chunk of candidate keys in LDS.
-// grid = (CAND_CHUNKS, frames, 2 detectors); chunks beyond the candidate count exit.
-__global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
+// Bitonic sort (descending) of one chunk of CHUNK candidate keys in LDS.
+// grid = (CAND_CAP / CHUNK, frames, 2 detectors); chunks beyond the candidate count exit.  THREADS: a power of two, at
+// most CHUNK / 2 (a pass of the network is a barrier of the whole workgroup: few wavefronts make it cheap).
+template <int CHUNK, int THREADS>
+__global__ __launch_bounds__(THREADS) void sort_chunk_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    const int det = blockIdx.z;
+    const int det = blockIdx.y;
     if (!(det_mask & (1 << det))) return;
-    const size_t list = (size_t)blockIdx.y * 2 + det;
+    const size_t list = (size_t)blockIdx.x * 2 + det;
     const int total = min(cand_count[list], CAND_CAP);
-    const int base = blockIdx.x * SORT_S;
+    const int base = blockIdx.z * CHUNK;
     if (base >= total) return;
-    const int nloc = min(SORT_S, total - base);
-    int S = 1024;
+    const int nloc = min(CHUNK, total - base);
+    int S = THREADS;
     while (S < nloc) S <<= 1;
     uint64_t *src = cand + list * CAND_CAP + base;
     const int tid = threadIdx.x;
-    for (int i = tid; i < S; i += 1024) keys[i] = (i < nloc) ? src[i] : 0ull;
+    for (int i = tid; i < S; i += THREADS) keys[i] = (i < nloc) ? src[i] : 0ull;
     __syncthreads();
     // The passes with partner distance below LB of a stage stay inside aligned blocks of LB keys: a thread
     // takes such a block into registers and runs them (for the stages up to LB: all of their passes) without a
-    // barrier in between.  S >= 1024, so every later stage has its direction constant over a block.
+    // barrier in between.  S >= THREADS >= 2 * LB, so every later stage has its direction constant over a block.
     constexpr int LB = 8;            // 16 measured slower: half the threads idle in the local phase
     auto local_passes = [&](int k_first, int k_last) {
-        for (int blk = tid; blk < S / LB; blk += 1024) {
+        for (int blk = tid; blk < S / LB; blk += THREADS) {
             uint64_t r[LB];
 #pragma unroll
             for (int q = 0; q < LB; ++q) r[q] = keys[LB * blk + q];
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const 
     auto strided_passes = [&](int k, int jhi, auto NP) {
         constexpr int np = decltype(NP)::value, nk = 1 << np;
         const int jlo = jhi >> (np - 1);
-        for (int t = tid; t < S / nk; t += 1024) {
+        for (int t = tid; t < S / nk; t += THREADS) {
             const int low = t & (jlo - 1), base = (t - low) * nk + low;
             const bool desc = (base & k) == 0;
             uint64_t r[nk];
@@ -631,39 +634,128 @@ __global__ __launch_bounds__(1024) void sort_chunk_kernel(uint64_t *cand, const 
         }
         local_passes(k, k);
     }
-    // write back the sorted chunk, padded to SORT_S with zeros so merges can read blindly
-    for (int i = tid; i < SORT_S; i += 1024) src[i] = (i < S) ? keys[i] : 0ull;
+    // write back the sorted chunk, padded to CHUNK with zeros so merges can read blindly
+    for (int i = tid; i < CHUNK; i += THREADS) src[i] = (i < S) ? keys[i] : 0ull;
 }
 
-// Merge sorted chunks c and c+step (both descending, zero padded) keeping the top SORT_S in chunk c.
-__global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, const int32_t *cand_count, int step, int det_mask)
+// The sorted parts (SORT_P keys each, descending, zero padded: sort_chunk_kernel<SORT_P>) of one SORT_S-chunk of a list
+// merged in LDS into one sorted chunk, zero padded to SORT_S.  Neighbouring sorted runs of m keys become runs of 2m:
+// one pass pairs key i of the first run with key m-1-i of the second (after it every key of the first half is at least
+// every key of the second and both halves are bitonic), then the passes with partner distance m/2 ... 1 sort the halves;
+// all comparisons point the same way, so the zeros at the end never move.  A list of n candidates thus has its first
+// sort spread over ceil(n / SORT_P) workgroups instead of one.
+// grid = (frames, 2 detectors, CAND_CHUNKS).
+constexpr int SORT_P = 2048;
+__global__ __launch_bounds__(1024) void merge_parts_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    const int det = blockIdx.z;
+    const int det = blockIdx.y;
     if (!(det_mask & (1 << det))) return;
-    const size_t list = (size_t)blockIdx.y * 2 + det;
+    const size_t list = (size_t)blockIdx.x * 2 + det;
     const int total = min(cand_count[list], CAND_CAP);
-    const int ca = blockIdx.x * 2 * step, cb = ca + step;
-    if (cb * SORT_S >= total) return;                   // partner chunk is empty
-    uint64_t *A = cand + list * CAND_CAP + (size_t)ca * SORT_S;
-    const uint64_t *B = cand + list * CAND_CAP + (size_t)cb * SORT_S;
+    const int base = blockIdx.z * SORT_S;
+    if (base >= total) return;
+    const int nparts = (min(SORT_S, total - base) + SORT_P - 1) / SORT_P;
+    uint64_t *src = cand + list * CAND_CAP + base;
     const int tid = threadIdx.x;
-    // max(A[i], B[S-1-i]) is the top-S set as a bitonic sequence
-    for (int i = tid; i < SORT_S; i += 1024) {
-        uint64_t x = A[i], y = B[SORT_S - 1 - i];
-        keys[i] = x > y ? x : y;
+    if (nparts == 1) {                                      // sorted already; the later merges read whole chunks
+        if (total > SORT_S)
+            for (int i = SORT_P + tid; i < SORT_S; i += 1024) src[i] = 0ull;
+        return;
     }
+    int M = 2 * SORT_P;
+    while (M < nparts * SORT_P) M <<= 1;
+    for (int i = tid; i < M; i += 1024) keys[i] = (i < nparts * SORT_P) ? src[i] : 0ull;
     __syncthreads();
-    for (int j = SORT_S >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < (SORT_S >> 1); t += 1024) {
-            int i = 2 * t - (t & (j - 1)), p = i + j;
-            uint64_t a = keys[i], b = keys[p];
-            if (a < b) { keys[i] = b; keys[p] = a; }
+    constexpr int LB = 8;
+    auto cmpx = [](uint64_t &a, uint64_t &b) { const uint64_t x = a, y = b; const bool sw = x < y; a = sw ? y : x; b = sw ? x : y; };
+    auto strided_passes = [&](int jhi, auto NP) {          // the passes jhi, jhi/2, ... (np of them) on 2^np keys per thread
+        constexpr int np = decltype(NP)::value, nk = 1 << np;
+        const int jlo = jhi >> (np - 1);
+        for (int t = tid; t < M / nk; t += 1024) {
+            const int low = t & (jlo - 1), b0 = (t - low) * nk + low;
+            uint64_t r[nk];
+#pragma unroll
+            for (int q = 0; q < nk; ++q) r[q] = keys[b0 + q * jlo];
+#pragma unroll
+            for (int jj = nk / 2; jj > 0; jj >>= 1) {
+#pragma unroll
+                for (int q = 0; q < nk; ++q)
+                    if ((q & jj) == 0) cmpx(r[q], r[q | jj]);
+            }
+#pragma unroll
+            for (int q = 0; q < nk; ++q) keys[b0 + q * jlo] = r[q];
         }
         __syncthreads();
+    };
+    for (int m = SORT_P; m < M; m <<= 1) {
+        for (int t = tid; t < (M >> 1); t += 1024) {
+            const int off = t & (m - 1), b0 = (t - off) * 2;
+            uint64_t a = keys[b0 + off], b = keys[b0 + 2 * m - 1 - off];
+            if (a < b) { keys[b0 + off] = b; keys[b0 + 2 * m - 1 - off] = a; }
+        }
+        __syncthreads();
+        int c = 0;
+        for (int j = m >> 1; j >= LB; j >>= 1) ++c;
+        for (int jhi = m >> 1; c > 0;) {
+            const int np = c < 3 ? c : 3;
+            if (np == 3) strided_passes(jhi, std::integral_constant<int, 3>());
+            else if (np == 2) strided_passes(jhi, std::integral_constant<int, 2>());
+            else strided_passes(jhi, std::integral_constant<int, 1>());
+            jhi >>= np; c -= np;
+        }
+        strided_passes(LB / 2, std::integral_constant<int, 3>());     // partner distances 4, 2, 1: eight neighbouring keys
+    }
+    for (int i = tid; i < SORT_S; i += 1024) src[i] = (i < M) ? keys[i] : 0ull;
+}
+
+// The top SORT_S keys of a list with more than one sorted chunk (each descending, zero padded), left sorted in chunk 0:
+// the later chunks are merged into it one after the other.  One launch, one workgroup per list; lists that fit one chunk
+// -- the rule -- leave at once.  grid = (frames, 2 detectors).
+__global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    const int det = blockIdx.y;
+    if (!(det_mask & (1 << det))) return;
+    const size_t list = (size_t)blockIdx.x * 2 + det;
+    const int total = min(cand_count[list], CAND_CAP);
+    if (total <= SORT_S) return;
+    uint64_t *A = cand + list * CAND_CAP;
+    const int tid = threadIdx.x;
+    for (int cb = 1; cb * SORT_S < total; ++cb) {
+        const uint64_t *B = A + (size_t)cb * SORT_S;
+        // max(A[i], B[S-1-i]) is the top-S set as a bitonic sequence
+        for (int i = tid; i < SORT_S; i += 1024) {
+            const uint64_t x = cb == 1 ? A[i] : keys[i], y = B[SORT_S - 1 - i];
+            keys[i] = x > y ? x : y;
+        }
+        __syncthreads();
+        for (int j = SORT_S >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (SORT_S >> 1); t += 1024) {
+                int i = 2 * t - (t & (j - 1)), p = i + j;
+                uint64_t a = keys[i], b = keys[p];
+                if (a < b) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
     }
     for (int i = tid; i < SORT_S; i += 1024) A[i] = keys[i];
+}
+
+// Every candidate list of a batch sorted by descending key, the leading SORT_S keys of each in place: parts of SORT_P keys
+// sorted side by side, merged per SORT_S-chunk in LDS, then the chunks of a long list merged keeping the top SORT_S.
+static void launch_sort_lists(hipStream_t s, uint64_t *cand, const int32_t *cand_count, int frames, int det_mask)
+{
+    static const bool whole = getenv("VSLAM_SORT_WHOLE") != nullptr;        // A/B runs: one workgroup per SORT_S-chunk
+    if (whole) {
+        hipLaunchKernelGGL((sort_chunk_kernel<SORT_S, 1024>), dim3(frames, 2, CAND_CHUNKS), dim3(1024), SORT_S * 8, s, cand, cand_count, det_mask);
+    } else {
+        hipLaunchKernelGGL((sort_chunk_kernel<SORT_P, 256>), dim3(frames, 2, CAND_CAP / SORT_P), dim3(256), SORT_P * 8, s, cand, cand_count, det_mask);
+        hipLaunchKernelGGL(merge_parts_kernel, dim3(frames, 2, CAND_CHUNKS), dim3(1024), SORT_S * 8, s, cand, cand_count, det_mask);
+    }
+    hipLaunchKernelGGL(merge_chunks_kernel, dim3(frames, 2), dim3(1024), SORT_S * 8, s, cand, cand_count, det_mask);
 }
 
 // Unpacks the leading keys of each list into Feature records.
@@ -1192,9 +1284,7 @@ static vslam_status launch_orb_level(vslam_ctx *ctx, const uint8_t *gray, int w,
     const size_t tiles = (size_t)a.tiles_x * ((h + FT_H - 1) / FT_H) * frames;
     if (tiles > 0x7fffffffu) return fail(ctx, VSLAM_ERR_CAPACITY, "orb_detect: too many tiles for one launch");
     hipLaunchKernelGGL(fast9_tile_kernel, dim3((unsigned)tiles), dim3(FT_T), 0, s, a);
-    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 1);
-    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
-        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, step, 1);
+    launch_sort_lists(s, a.cand, a.cand_count, frames, 1);
     hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 0, 2 * nfeatures, kept);
     OrbHarrisArgs ha;
     ha.gray = gray; ha.stride_frame = stride_frame; ha.w = w; ha.h = h; ha.stride = stride; ha.block = block; ha.k = harris_k;
@@ -1209,7 +1299,7 @@ static vslam_status launch_orb_level(vslam_ctx *ctx, const uint8_t *gray, int w,
     const bool words = block == 7 && ((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)stride | (uintptr_t)stride_frame) & 3) == 0;
     if (words) hipLaunchKernelGGL(orb_harris7_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
     else hipLaunchKernelGGL(orb_harris_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
-    hipLaunchKernelGGL(sort_chunk_kernel, dim3(1, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 2);
+    hipLaunchKernelGGL((sort_chunk_kernel<SORT_S, 1024>), dim3(frames, 2, 1), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 2);
     hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 1, nfeatures, kept + frames);
     const int lim = cap < SORT_S ? cap : SORT_S;
     hipLaunchKernelGGL(orb_emit_kernel, dim3((lim + 255) / 256, frames), dim3(256), 0, s, a.cand, kept + frames, cap, out, count);
@@ -1303,10 +1393,7 @@ static vslam_status launch_detect(vslam_ctx *ctx, CornerArgs a, int frames, int 
         else hipLaunchKernelGGL((corner_tile_kernel<3, false, 0>), grid, dim3(256), lds, s, a);
     }
     VSLAM_HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, det_mask);
-    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
-        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s,
-                           a.cand, a.cand_count, step, det_mask);
+    launch_sort_lists(s, a.cand, a.cand_count, frames, det_mask);
     VSLAM_HIP_TRY(ctx, hipGetLastError());
     const int ndet = detector == 2 ? 2 : 1, det_first = detector == 2 ? 0 : detector;
     const int lim = cap < p->max_features ? cap : p->max_features;
@@ -1327,10 +1414,7 @@ static vslam_status launch_fast9(vslam_ctx *ctx, FastArgs a, int frames, int max
     const size_t tiles = (size_t)a.tiles_x * ((a.h + FT_H - 1) / FT_H) * frames;
     if (tiles > 0x7fffffffu) return fail(ctx, VSLAM_ERR_CAPACITY, "fast9_detect: too many tiles for one launch");
     hipLaunchKernelGGL(fast9_tile_kernel, dim3((unsigned)tiles), dim3(FT_T), 0, s, a);
-    hipLaunchKernelGGL(sort_chunk_kernel, dim3(CAND_CHUNKS, frames, 2), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 1);
-    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
-        hipLaunchKernelGGL(merge_chunks_kernel, dim3(CAND_CHUNKS / (2 * step), frames, 2), dim3(1024), SORT_S * 8, s,
-                           a.cand, a.cand_count, step, 1);
+    launch_sort_lists(s, a.cand, a.cand_count, frames, 1);
     const int lim = cap < max_features ? cap : max_features;
     hipLaunchKernelGGL(emit_features_kernel, dim3((lim + 255) / 256, frames, 1), dim3(256), 0, s, a.cand, a.cand_count,
                        0, 1, cap, max_features, out, count);
@@ -1352,7 +1436,8 @@ static vslam_status ensure_lds_attr(vslam_ctx *ctx)
     // The attribute belongs to the function on the current device: one flag per context (a context is bound
     // to one device and is not used from two threads at once).
     if (ctx->corner_lds_attr_set) return VSLAM_OK;
-    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sort_chunk_kernel<SORT_S, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
+    VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_parts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     VSLAM_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_chunks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SORT_S * 8));
     const int big = (int)tile_lds_bytes(2 * MAXHB + 1);
     const void *tile_kernels[] = {
