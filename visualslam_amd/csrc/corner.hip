@@ -710,10 +710,9 @@ __global__ __launch_bounds__(1024) void merge_parts_kernel(uint64_t *cand, const
     for (int i = tid; i < SORT_S; i += 1024) src[i] = (i < M) ? keys[i] : 0ull;
 }
 
-// The top SORT_S keys of a list with more than one sorted chunk (each descending, zero padded), left sorted in chunk 0:
-// the later chunks are merged into it one after the other.  One launch, one workgroup per list; lists that fit one chunk
-// -- the rule -- leave at once.  grid = (frames, 2 detectors).
-__global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, const int32_t *cand_count, int det_mask)
+// Merge sorted chunks c and c+step (both descending, zero padded) keeping the top SORT_S in chunk c.
+// grid = (frames, 2 detectors, pairs of chunks); lists that fit one chunk -- the rule -- leave at once.
+__global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, const int32_t *cand_count, int step, int det_mask)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
@@ -721,32 +720,32 @@ __global__ __launch_bounds__(1024) void merge_chunks_kernel(uint64_t *cand, cons
     if (!(det_mask & (1 << det))) return;
     const size_t list = (size_t)blockIdx.x * 2 + det;
     const int total = min(cand_count[list], CAND_CAP);
-    if (total <= SORT_S) return;
-    uint64_t *A = cand + list * CAND_CAP;
+    const int ca = blockIdx.z * 2 * step, cb = ca + step;
+    if (cb * SORT_S >= total) return;                   // partner chunk is empty
+    uint64_t *A = cand + list * CAND_CAP + (size_t)ca * SORT_S;
+    const uint64_t *B = cand + list * CAND_CAP + (size_t)cb * SORT_S;
     const int tid = threadIdx.x;
-    for (int cb = 1; cb * SORT_S < total; ++cb) {
-        const uint64_t *B = A + (size_t)cb * SORT_S;
-        // max(A[i], B[S-1-i]) is the top-S set as a bitonic sequence
-        for (int i = tid; i < SORT_S; i += 1024) {
-            const uint64_t x = cb == 1 ? A[i] : keys[i], y = B[SORT_S - 1 - i];
-            keys[i] = x > y ? x : y;
+    // max(A[i], B[S-1-i]) is the top-S set as a bitonic sequence
+    for (int i = tid; i < SORT_S; i += 1024) {
+        uint64_t x = A[i], y = B[SORT_S - 1 - i];
+        keys[i] = x > y ? x : y;
+    }
+    __syncthreads();
+    for (int j = SORT_S >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (SORT_S >> 1); t += 1024) {
+            int i = 2 * t - (t & (j - 1)), p = i + j;
+            uint64_t a = keys[i], b = keys[p];
+            if (a < b) { keys[i] = b; keys[p] = a; }
         }
         __syncthreads();
-        for (int j = SORT_S >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (SORT_S >> 1); t += 1024) {
-                int i = 2 * t - (t & (j - 1)), p = i + j;
-                uint64_t a = keys[i], b = keys[p];
-                if (a < b) { keys[i] = b; keys[p] = a; }
-            }
-            __syncthreads();
-        }
     }
     for (int i = tid; i < SORT_S; i += 1024) A[i] = keys[i];
 }
 
 // Every candidate list of a batch sorted by descending key, the leading SORT_S keys of each in place: parts of SORT_P keys
-// sorted side by side, merged per SORT_S-chunk in LDS, then the chunks of a long list merged keeping the top SORT_S.
-static void launch_sort_lists(hipStream_t s, uint64_t *cand, const int32_t *cand_count, int frames, int det_mask)
+// sorted side by side, merged per SORT_S-chunk in LDS, then the chunks of a long list merged pairwise keeping the top SORT_S.
+// one_chunk: the caller knows that no list holds more than SORT_S keys (the chunk merges are then not launched).
+static void launch_sort_lists(hipStream_t s, uint64_t *cand, const int32_t *cand_count, int frames, int det_mask, bool one_chunk = false)
 {
     static const bool whole = getenv("VSLAM_SORT_WHOLE") != nullptr;        // A/B runs: one workgroup per SORT_S-chunk
     if (whole) {
@@ -755,7 +754,9 @@ static void launch_sort_lists(hipStream_t s, uint64_t *cand, const int32_t *cand
         hipLaunchKernelGGL((sort_chunk_kernel<SORT_P, 256>), dim3(frames, 2, CAND_CAP / SORT_P), dim3(256), SORT_P * 8, s, cand, cand_count, det_mask);
         hipLaunchKernelGGL(merge_parts_kernel, dim3(frames, 2, CAND_CHUNKS), dim3(1024), SORT_S * 8, s, cand, cand_count, det_mask);
     }
-    hipLaunchKernelGGL(merge_chunks_kernel, dim3(frames, 2), dim3(1024), SORT_S * 8, s, cand, cand_count, det_mask);
+    if (one_chunk) return;
+    for (int step = 1; step < CAND_CHUNKS; step <<= 1)
+        hipLaunchKernelGGL(merge_chunks_kernel, dim3(frames, 2, CAND_CHUNKS / (2 * step)), dim3(1024), SORT_S * 8, s, cand, cand_count, step, det_mask);
 }
 
 // Unpacks the leading keys of each list into Feature records.
@@ -1299,7 +1300,7 @@ static vslam_status launch_orb_level(vslam_ctx *ctx, const uint8_t *gray, int w,
     const bool words = block == 7 && ((reinterpret_cast<uintptr_t>(gray) | (uintptr_t)stride | (uintptr_t)stride_frame) & 3) == 0;
     if (words) hipLaunchKernelGGL(orb_harris7_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
     else hipLaunchKernelGGL(orb_harris_kernel, dim3(SORT_S / 256, frames), dim3(256), 0, s, ha);
-    hipLaunchKernelGGL((sort_chunk_kernel<SORT_S, 1024>), dim3(frames, 2, 1), dim3(1024), SORT_S * 8, s, a.cand, a.cand_count, 2);
+    launch_sort_lists(s, a.cand, a.cand_count, frames, 2, /*one_chunk=*/true);      // at most 2 * nfeatures <= SORT_S keys
     hipLaunchKernelGGL(orb_cut_kernel, dim3(frames), dim3(1024), 0, s, a.cand, a.cand_count, 1, nfeatures, kept + frames);
     const int lim = cap < SORT_S ? cap : SORT_S;
     hipLaunchKernelGGL(orb_emit_kernel, dim3((lim + 255) / 256, frames), dim3(256), 0, s, a.cand, kept + frames, cap, out, count);
