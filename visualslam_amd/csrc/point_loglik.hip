@@ -249,10 +249,15 @@ __global__ __launch_bounds__(kTermThreads) void loglik_terms_kernel(CamK cam, Te
     double acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    // the landmark, its measurement and its flag are requested before the pose's sines and cosines are worked out: one
+    // trip to memory on the wave's critical path instead of two
+    const int jc = min(j, L - 1);
+    const double rl[3] = {x[12 + 3 * jc], x[12 + 3 * jc + 1], x[12 + 3 * jc + 2]}, yl[2] = {y[2 * jc], y[2 * jc + 1]};
+    const bool seen = vis[jc] != 0;
     const Pose pose = make_pose_wave(x + 6);
     if (j < L) {
         Terms tm;
-        landmark_terms<2>(cam, pose, x + 12 + 3 * j, y + 2 * j, vis[j] != 0, a.is2, a.lconst, tm);
+        landmark_terms<2>(cam, pose, rl, yl, seen, a.is2, a.lconst, tm);
         acc[0] = tm.ell;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { acc[1 + i] = tm.gr[i]; acc[4 + i] = tm.gT[i]; g[12 + 3 * j + i] = tm.gr[i]; }
